@@ -1,0 +1,60 @@
+"""GPU parity: HIP detector vs the CPU oracle, bit-exact (integer pipeline) through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames():
+    from vbt_amd import synth
+    return np.concatenate([synth.clip_frames(s, 11 * s, 2) for s in range(3)])   # 6 frames, 3 clips
+
+
+@pytest.fixture(scope="module")
+def oracle_run(oracle_lib, model_path, frames):
+    det = oracle_lib.OracleDetector(model_path)
+    outs, tensors = [], []
+    for f in frames:
+        outs.append(det.run(f))
+        tensors.append([det.tensor(t) for t in range(1, det.num_tensors - 1)])
+    return outs, tensors
+
+
+def test_every_tensor_bit_exact(model_path, frames, oracle_run):
+    from vbt_amd.interpreter import Interpreter
+    outs, tensors = oracle_run
+    B = len(frames)
+    it = Interpreter(model_path, max_batch=B)
+    boxes, scores, classes, counts = it.detect(frames)
+    bad = []
+    for tid in range(1, it.num_tensors() - 1):
+        got = it.read_tensor(tid, B)
+        for b in range(B):
+            if not np.array_equal(got[b], tensors[b][tid - 1]):
+                d = np.abs(got[b].astype(int) - tensors[b][tid - 1].astype(int))
+                bad.append((tid, b, int(d.max()), float((d > 0).mean())))
+                break
+    assert not bad, f"first mismatching tensors (id, frame, max|diff|, frac): {bad[:8]}"
+    for b in range(B):
+        ob, os_, oc, on = outs[b]
+        assert counts[b] == on
+        assert np.array_equal(scores[b], os_)
+        assert np.array_equal(boxes[b], ob)
+        assert np.array_equal(classes[b], oc)
+
+
+def test_batch_tail_and_single_frame(model_path, frames, oracle_run):
+    """B=1 (the reference's call shape) and a batch smaller than max_batch."""
+    from vbt_amd.interpreter import Interpreter
+    outs, _ = oracle_run
+    it = Interpreter(model_path, max_batch=4)
+    run = it.get_signature_runner()
+    out = run(images=frames[2:3])
+    ob, os_, oc, on = outs[2]
+    assert int(np.squeeze(out["output_0"])) == on
+    assert np.array_equal(np.squeeze(out["output_1"]), os_)
+    assert np.array_equal(np.squeeze(out["output_3"]), ob)
+    b3 = it.detect(frames[:3])
+    for b in range(3):
+        assert b3[3][b] == outs[b][3] and np.array_equal(b3[0][b], outs[b][0])

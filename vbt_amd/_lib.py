@@ -1,0 +1,58 @@
+"""ctypes binding of libvbt_hip.so (include/vbt_hip.h).  There is no CPU fallback: if the
+HIP library is missing this module raises, loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvbt_hip.so")
+_lib = None
+
+c_void_p, c_int, c_char_p, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_double
+
+
+class VbtError(RuntimeError):
+    pass
+
+
+class KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("launches", c_int), ("algorithmic_bytes", c_double), ("macs", c_double)]
+
+
+_SIGS = {
+    "vbt_last_error": (c_char_p, []),
+    "vbt_device_count": (c_int, []),
+    "vbt_model_create": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "vbt_model_destroy": (None, [c_void_p]),
+    "vbt_model_input_shape": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "vbt_model_num_tensors": (c_int, [c_void_p]),
+    "vbt_model_num_ops": (c_int, [c_void_p]),
+    "vbt_model_tensor_shape": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int)]),
+    "vbt_detect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "vbt_detect_async": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vbt_model_read_tensor": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "vbt_model_kernel_stats": (c_int, [c_void_p, c_int, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),
+    "vbt_model_profile": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_double), c_int]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VbtError(f"{LIB_PATH} is missing: build it with `python -m vbt_amd.build` "
+                           "(__graft_entry__.build()). vbt_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the library does not export the symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def declared_symbols():
+    return list(_SIGS)
+
+
+def check(rc):
+    if rc != 0:
+        raise VbtError(f"libvbt_hip error {rc}: {lib().vbt_last_error().decode()}")
