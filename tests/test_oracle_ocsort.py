@@ -79,7 +79,8 @@ def test_row_order_and_ids(replays):
     g, o = replays["001"]
     t0 = o["time"][0]
     assert list(o["id"][o["time"] == t0]) == [2, 1]
-    assert list(g["id"][g["time"] == t0]) == [2, 1]
+    order = np.argsort(g["index"])                   # the stored frame is sorted by (id,time); index = emission order
+    assert list(g["id"][order][:4]) == [2, 1, 2, 1]
     assert list(g["index"][:4]) == [1, 3, 5, 7]     # id 1 keeps the odd original row labels after the (id,time) sort
 
 
