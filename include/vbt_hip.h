@@ -86,6 +86,65 @@ int vbt_model_kernel_stats(const vbt_model* m, int B, vbt_kernel_stat* out, int 
 int vbt_model_profile(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream,
                       double* ms_out, int cap);
 
+/* ------------------------------------------------------------------ tracker -----------------
+ * Replaces ocsort.OCSort (reference track.py:17,157,186-199), the row assembly of
+ * reference track.py:189-234 and the export id selection of track.py:107-115.
+ * One handle tracks `n_clips` independent clips in parallel (one wavefront per clip).
+ */
+typedef struct vbt_tracker vbt_tracker;
+typedef struct {
+  int32_t max_age;       /* reference track.py:22,157 -> 30 */
+  int32_t min_hits;      /* OC-SORT default 3 */
+  int32_t delta_t;       /* OC-SORT default 3 (1..3 supported) */
+  int32_t asso;          /* second-round association: 0 = iou, 1 = diou (reference track.py:157) */
+  double iou_threshold;  /* reference track.py:157 -> 0.1 */
+  double inertia;        /* OC-SORT default 0.2 */
+  double det_thresh;     /* OC-SORT score gate (detections with score <= det_thresh are dropped) */
+} vbt_tracker_params;
+
+/* rows_cap: capacity of the per-clip row log (rows = emitted (id,time,...) records). */
+int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* p, int device, vbt_tracker** out);
+void vbt_tracker_destroy(vbt_tracker* t);
+int vbt_tracker_reset(vbt_tracker* t);
+
+/* OCSort.update for F consecutive frames of every clip (host pointers; synchronous):
+ *   dets   float64 [F][n_clips][25][6] = x1,y1,x2,y2,score,cls   (reference odt.py:102-118)
+ *   counts int32   [F][n_clips]   (0 = empty frame: the tracker is not stepped, track.py:180-181)
+ *   times  float64 [F][n_clips]   (frame_count / fps, reference track.py:169) */
+int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts, const double* times, int F);
+
+/* Fused path: one frame per clip straight from vbt_detect_async's device outputs; applies the
+ * detection threshold of reference odt.py:70-75 (score >= det_threshold). times_host [n_clips]. */
+int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, const float* scores_dev,
+                                       const int32_t* counts_dev, const double* times_host, float det_threshold,
+                                       void* stream);
+
+/* What OCSort.update returned for the clip's most recent stepped frame: out7 [M,7] =
+ * x1,y1,x2,y2,id(1-based),cls,score (reference track.py:190) and vel2 [M,2] = kf.x[4:6] of the
+ * same track (reference track.py:194-199). */
+int vbt_tracker_last_output(vbt_tracker* t, int clip, double* out7, double* vel2, int cap, int* M);
+/* tracker.trackers: ids (0-based, reference track.py:195) and kf.x (7 values each) in list order */
+int vbt_tracker_get_trackers(vbt_tracker* t, int clip, int32_t* ids, double* kfx, int cap, int* n);
+int vbt_tracker_status(vbt_tracker* t, int clip, int32_t* n_rows, int32_t* n_trackers, int32_t* overflow,
+                       int32_t* rows_overflow, int32_t* frame_count);
+/* The clip's row log in emission order = the dict of reference track.py:144-145,227-234:
+ * id int64 [n]; cols7 float64 [n,7] = time,x,y,dx,dy,norm_plate_height,norm_plate_width */
+int vbt_tracker_rows(vbt_tracker* t, int clip, int64_t* id, double* cols7, int cap, int* n);
+
+/* End of clips: pick each clip's id with the largest cumulative path length (reference
+ * track.py:107-115) and run plot.py's preprocessing + VelocityTracker over its rows on device. */
+int vbt_tracker_finish(vbt_tracker* t, double plate_diameter, double diff_threshold, double min_distance, void* stream);
+/* phases6 [P,6] = time_start,time_end,y_start,y_end,rom,type (reference Phase.py:16-22) */
+int vbt_tracker_phases(vbt_tracker* t, int clip, int32_t* best_id, double* phases6, int cap, int* P);
+
+/* ------------------------------------------------------------------ rep analysis ------------
+ * Replaces VelocityTracker (reference VelocityTracker.py:15-230) as driven by analyze_df
+ * (reference plot.py:33-47): cols7 [T,7] = time,x,y,dx,dy,norm_plate_height,norm_plate_width
+ * of one track. preprocess != 0 applies plot.py:90-95 (rolling(5)/expanding means) first;
+ * flush != 0 runs end_processing(). */
+int vbt_analyze(const double* cols7, int T, int preprocess, int flush, double plate_diameter, double diff_threshold,
+                double min_distance, double* phases6, int cap, int* P, int device);
+
 #ifdef __cplusplus
 }
 #endif

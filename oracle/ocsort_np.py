@@ -242,7 +242,9 @@ def associate(dets, trks, iou_threshold, velocities, previous_obs, vdc_weight):
     valid = np.ones(previous_obs.shape[0])
     valid[np.where(previous_obs[:, 4] < 0)] = 0
     iou_matrix = iou_batch(dets, trks)               # [det, trk]
-    scores = np.repeat(dets[:, -1][:, None], trks.shape[0], axis=1)
+    # OC-SORT weights the direction term by the detection SCORE (column 4 of [x1,y1,x2,y2,score,cls]; the
+    # original takes `detections[:, -1]` of 5-column detections)
+    scores = np.repeat(dets[:, 4][:, None], trks.shape[0], axis=1)
     angle_cost = ((valid[:, None] * diff_angle) * vdc_weight).T * scores
     if min(iou_matrix.shape) > 0:
         a = (iou_matrix > iou_threshold).astype(np.int32)

@@ -14,6 +14,11 @@ class VbtError(RuntimeError):
     pass
 
 
+class TrackerParams(ctypes.Structure):
+    _fields_ = [("max_age", ctypes.c_int32), ("min_hits", ctypes.c_int32), ("delta_t", ctypes.c_int32),
+                ("asso", ctypes.c_int32), ("iou_threshold", c_double), ("inertia", c_double), ("det_thresh", c_double)]
+
+
 class KernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 32), ("launches", c_int), ("algorithmic_bytes", c_double), ("macs", c_double)]
 
@@ -32,6 +37,18 @@ _SIGS = {
     "vbt_model_read_tensor": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "vbt_model_kernel_stats": (c_int, [c_void_p, c_int, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),
     "vbt_model_profile": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_double), c_int]),
+    "vbt_tracker_create": (c_int, [c_int, c_int, ctypes.POINTER(TrackerParams), c_int, ctypes.POINTER(c_void_p)]),
+    "vbt_tracker_destroy": (None, [c_void_p]),
+    "vbt_tracker_reset": (c_int, [c_void_p]),
+    "vbt_tracker_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "vbt_tracker_update_from_detections": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p]),
+    "vbt_tracker_last_output": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_int)]),
+    "vbt_tracker_get_trackers": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_int)]),
+    "vbt_tracker_status": (c_int, [c_void_p, c_int] + [ctypes.POINTER(ctypes.c_int32)] * 5),
+    "vbt_tracker_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, ctypes.POINTER(c_int)]),
+    "vbt_tracker_finish": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p]),
+    "vbt_tracker_phases": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_int32), c_void_p, c_int, ctypes.POINTER(c_int)]),
+    "vbt_analyze": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_void_p, c_int, ctypes.POINTER(c_int), c_int]),
 }
 
 

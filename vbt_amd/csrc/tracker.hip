@@ -1,0 +1,1092 @@
+// On-device OC-SORT tracker, row assembly and rep analysis for gfx950 (MI355X).
+//
+// Replaces, per clip (reference track.py:157-234, plot.py:33-47,87-95):
+//   ocsort.OCSort(max_age=30, asso_func="diou", iou_threshold=0.1).update(dets, [])   track.py:157,186
+//   the kf.x[4:6] read-back and the 8-column row assembly                               track.py:189-234
+//   the max-cumulative-distance id selection of the export                              track.py:107-115
+//   rolling(5)/expanding means + VelocityTracker scan                                  plot.py:87-95,33-47
+// Execution model: ONE WAVEFRONT PER CLIP (clips are independent, frames of a clip are strictly
+// sequential: Kalman + phase state).  Lane t owns live tracker t (<= 64 per clip): predict, IoU /
+// direction-cost columns, Kalman update and row emission are lane-parallel; the linear assignment
+// is a shortest-augmenting-path solver with lanes = columns and wave min-reductions; list
+// maintenance (births, deletions) uses ballots.  All arithmetic is FP64 with contraction off and
+// follows the op order of the numpy formulation, so the Kalman velocities are bit-identical to
+// the reference's committed DataFrames (tests/test_gpu_tracker.py).
+//   The 7-state SORT filter decouples into three (position, velocity) 2x2 filters (cx, cy, s) and a
+// scalar one (r): F/H/Q/R never couple them, so the dense 7x7 products of the numpy formulation
+// reduce EXACTLY (same roundings; the dropped terms are exact zeros) to the closed forms below.
+#include "common.h"
+
+namespace vbt {
+
+constexpr int MAXT = 64;
+constexpr int MAXD = VBT_MAX_DETECTIONS;
+constexpr int MAXPH = 512;  // phases kept per clip
+
+struct Trk {
+  double x[7];
+  double B[3][4];  // covariance blocks (a b; c d) of (cx,vcx) (cy,vcy) (s,vs)
+  double Pr;       // variance of r
+  double sx[7], sB[3][4], sPr;  // frozen copy (observation-centric re-update)
+  double last_z[4];
+  double last_obs[5];
+  double vel[2];
+  double obs[4][5];  // observations keyed by age & 3
+  double conf, cls;
+  double cum, cum_c, prev_x, prev_y;  // running path length of the emitted rows (export id selection)
+  int obs_age[4];
+  int has_saved, observed, gap, has_obs, has_vel;
+  int time_since_update, id, hits, hit_streak, age, nrows;
+};
+
+struct Row {
+  long long id;
+  double time, x, y, dx, dy, h, w;
+};
+
+struct ClipState {
+  int ntrk, frame_count, next_id, overflow, nrows, rows_overflow, best_id, last_n;
+  double best_cum;
+  int order[MAXT];
+  unsigned long long used;  // slot bitmap
+  double last_out[MAXD][9];  // last update(): x1,y1,x2,y2,id,cls,score,dx,dy
+  Trk trk[MAXT];
+};
+
+struct TrackParams {
+  int max_age, min_hits, delta_t, asso;
+  double iou_thr, inertia, det_thresh;
+};
+
+// ------------------------------------------------------------------------------------------
+// Kalman filter pieces (see header comment)
+// ------------------------------------------------------------------------------------------
+__device__ inline void kf_predict(Trk& k, double q44, double q66) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) k.x[i] = k.x[i] + k.x[i + 4];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double a = k.B[i][0], b = k.B[i][1], c = k.B[i][2], d = k.B[i][3];
+    double qv = i == 2 ? q66 : q44;
+    k.B[i][0] = ((a + c) + (b + d)) + 1.0;
+    k.B[i][1] = (b + d) + 0.0;
+    k.B[i][2] = (c + d) + 0.0;
+    k.B[i][3] = d + qv;
+  }
+  k.Pr = k.Pr + 1.0;
+}
+
+__device__ inline void kf_update_math(Trk& k, const double z[4]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double Rc = i == 2 ? 10.0 : 1.0;
+    double a = k.B[i][0], b = k.B[i][1], c = k.B[i][2], d = k.B[i][3];
+    double y = z[i] - k.x[i];
+    double S = a + Rc;
+    double si = 1.0 / S;
+    double kp = a * si, kv = c * si;
+    k.x[i] = k.x[i] + kp * y;
+    k.x[i + 4] = k.x[i + 4] + kv * y;
+    double omk = 1.0 - kp, nkv = 0.0 - kv;
+    double M00 = omk * a, M01 = omk * b, M10 = nkv * a + c, M11 = nkv * b + d;
+    double N00 = M00 * omk, N01 = M00 * nkv + M01, N10 = M10 * omk, N11 = M10 * nkv + M11;
+    double KRp = kp * Rc, KRv = kv * Rc;
+    k.B[i][0] = N00 + KRp * kp;
+    k.B[i][1] = N01 + KRp * kv;
+    k.B[i][2] = N10 + KRv * kp;
+    k.B[i][3] = N11 + KRv * kv;
+  }
+  double y = z[3] - k.x[3];
+  double S = k.Pr + 10.0;
+  double si = 1.0 / S;
+  double kk = k.Pr * si;
+  k.x[3] = k.x[3] + kk * y;
+  double omk = 1.0 - kk;
+  k.Pr = (omk * k.Pr) * omk + (kk * 10.0) * kk;
+}
+
+// kf.update(z) with OC-SORT's freeze / unfreeze (observation-centric re-update)
+__device__ inline void kf_update(Trk& k, const double* z, double q44, double q66) {
+  k.gap += 1;  // one more entry in history_obs since the last real observation
+  if (z == nullptr) {
+    if (k.observed) {  // first miss: freeze
+#pragma unroll
+      for (int i = 0; i < 7; i++) k.sx[i] = k.x[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) k.sB[i][j] = k.B[i][j];
+      k.sPr = k.Pr;
+      k.has_saved = 1;
+    }
+    k.observed = 0;
+    return;
+  }
+  double zl[4] = {z[0], z[1], z[2], z[3]};
+  if (!k.observed && k.has_saved) {  // unfreeze: replay a linear virtual trajectory over the gap
+#pragma unroll
+    for (int i = 0; i < 7; i++) k.x[i] = k.sx[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) k.B[i][j] = k.sB[i][j];
+    k.Pr = k.sPr;
+    double x1 = k.last_z[0], y1 = k.last_z[1], s1 = k.last_z[2], r1 = k.last_z[3];
+    double w1 = sqrt(s1 * r1), h1 = sqrt(s1 / r1);
+    double x2 = z[0], y2 = z[1], s2 = z[2], r2 = z[3];
+    double w2 = sqrt(s2 * r2), h2 = sqrt(s2 / r2);
+    const int gap = k.gap;
+    const double g = (double)gap;
+    double dx = (x2 - x1) / g, dy = (y2 - y1) / g, dw = (w2 - w1) / g, dh = (h2 - h1) / g;
+    for (int i = 0; i < gap; i++) {
+      double f = (double)(i + 1);
+      double xx = x1 + f * dx, yy = y1 + f * dy, ww = w1 + f * dw, hh = h1 + f * dh;
+      double vz[4] = {xx, yy, ww * hh, ww / hh};
+      kf_update_math(k, vz);
+      if (i != gap - 1) kf_predict(k, q44, q66);
+      else { zl[0] = vz[0]; zl[1] = vz[1]; zl[2] = vz[2]; zl[3] = vz[3]; }  // history ends with the virtual box
+    }
+    k.has_saved = 0;
+  }
+  k.observed = 1;
+  kf_update_math(k, z);
+  k.last_z[0] = zl[0]; k.last_z[1] = zl[1]; k.last_z[2] = zl[2]; k.last_z[3] = zl[3];
+  k.gap = 0;
+}
+
+__device__ inline void bbox_to_z(const double* b, double z[4]) {
+  double w = b[2] - b[0], h = b[3] - b[1];
+  z[0] = b[0] + w / 2.0;
+  z[1] = b[1] + h / 2.0;
+  z[2] = w * h;
+  z[3] = w / (h + 1e-6);
+}
+__device__ inline void x_to_bbox(const double* x, double o[4]) {
+  double w = sqrt(x[2] * x[3]);
+  double h = x[2] / w;
+  o[0] = x[0] - w / 2.0; o[1] = x[1] - h / 2.0; o[2] = x[0] + w / 2.0; o[3] = x[1] + h / 2.0;
+}
+
+// `last_observation.sum() < 0` is how OC-SORT asks "no observation yet" (placeholder = five -1s); it
+// also fires for a real box far enough outside the image, and that quirk is kept.
+__device__ inline bool obs_sum_negative(const Trk& k) {
+  double s = k.last_obs[0];
+  s = s + k.last_obs[1]; s = s + k.last_obs[2]; s = s + k.last_obs[3]; s = s + k.last_obs[4];
+  return s < 0.0;
+}
+
+// KalmanBoxTracker.update(bbox)   (bbox = x1,y1,x2,y2,score ; cls)
+__device__ inline void trk_update(Trk& k, const double* det, double q44, double q66, int delta_t) {
+  if (det == nullptr) { kf_update(k, nullptr, q44, q66); return; }
+  k.conf = det[4];
+  k.cls = det[5];
+  if (!obs_sum_negative(k)) {
+    const double* prev = nullptr;
+    for (int i = 0; i < delta_t; i++) {
+      int a = k.age - (delta_t - i);
+      if (a >= 0 && k.obs_age[a & 3] == a) { prev = k.obs[a & 3]; break; }
+    }
+    if (!prev) prev = k.last_obs;
+    double cx1 = (prev[0] + prev[2]) / 2.0, cy1 = (prev[1] + prev[3]) / 2.0;
+    double cx2 = (det[0] + det[2]) / 2.0, cy2 = (det[1] + det[3]) / 2.0;
+    double sy = cy2 - cy1, sx = cx2 - cx1;
+    double norm = sqrt(sy * sy + sx * sx) + 1e-6;
+    k.vel[0] = sy / norm;
+    k.vel[1] = sx / norm;
+    k.has_vel = 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) { k.last_obs[i] = det[i]; k.obs[k.age & 3][i] = det[i]; }
+  k.obs_age[k.age & 3] = k.age;
+  k.has_obs = 1;
+  k.time_since_update = 0;
+  k.hits += 1;
+  k.hit_streak += 1;
+  double z[4];
+  bbox_to_z(det, z);
+  kf_update(k, z, q44, q66);
+}
+
+__device__ inline double iou_xyxy(const double* a, const double* b) {
+  double xx1 = fmax(a[0], b[0]), yy1 = fmax(a[1], b[1]), xx2 = fmin(a[2], b[2]), yy2 = fmin(a[3], b[3]);
+  double w = fmax(0.0, xx2 - xx1), h = fmax(0.0, yy2 - yy1);
+  double wh = w * h;
+  return wh / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - wh);
+}
+__device__ inline double diou_xyxy(const double* a, const double* b) {
+  double iou = iou_xyxy(a, b);
+  double cx1 = (a[0] + a[2]) / 2.0, cy1 = (a[1] + a[3]) / 2.0, cx2 = (b[0] + b[2]) / 2.0, cy2 = (b[1] + b[3]) / 2.0;
+  double ex = cx1 - cx2, ey = cy1 - cy2;
+  double inner = ex * ex + ey * ey;
+  double xc1 = fmin(a[0], b[0]), yc1 = fmin(a[1], b[1]), xc2 = fmax(a[2], b[2]), yc2 = fmax(a[3], b[3]);
+  double ox = xc2 - xc1, oy = yc2 - yc1;
+  double outer = ox * ox + oy * oy;
+  return (iou - inner / outer + 1.0) / 2.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave-parallel rectangular linear assignment (n rows <= m cols <= 64, lanes = columns).
+// cost(i, j) = tr ? C[j*ld + i] : C[i*ld + j].  Writes row2col[0..n).
+// ------------------------------------------------------------------------------------------
+struct LapShared {
+  double u[MAXT + 1];
+  int p[MAXT + 1];
+  int way[MAXT + 1];
+};
+
+__device__ inline void wave_argmin(double v, int lane, double& vmin, int& imin) {
+  double bv = v;
+  int bi = lane;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(bv, o);
+    int oi = __shfl_xor(bi, o);
+    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  vmin = bv;
+  imin = bi;
+}
+
+__device__ void lap_solve(const double* C, int ld, bool tr, int n, int m, int* row2col, LapShared& S, int lane) {
+  const double INF = 1e300;
+  double v = 0.0;
+  if (lane <= n) S.u[lane] = 0.0;
+  S.p[lane + 1] = 0;
+  if (lane == 0) S.p[0] = 0;
+  __syncthreads();
+  for (int i = 1; i <= n; i++) {
+    if (lane == 0) S.p[0] = i;
+    __syncthreads();
+    int j0 = 0;
+    double minv = INF;
+    bool used = false;
+    while (true) {
+      if (j0 > 0 && lane == j0 - 1) used = true;
+      int i0 = S.p[j0];
+      double ui0 = S.u[i0];
+      double cur = INF;
+      if (lane < m && !used) {
+        double c = (tr ? C[lane * ld + (i0 - 1)] : C[(i0 - 1) * ld + lane]) - ui0 - v;
+        if (c < minv) { minv = c; S.way[lane + 1] = j0; }
+        cur = minv;
+      }
+      double delta;
+      int jl;
+      wave_argmin(cur, lane, delta, jl);
+      __syncthreads();
+      if (lane < m) {
+        if (used) { S.u[S.p[lane + 1]] += delta; v -= delta; }
+        else minv -= delta;
+      }
+      if (lane == 0) S.u[S.p[0]] += delta;
+      __syncthreads();
+      j0 = jl + 1;
+      if (S.p[j0] == 0) break;
+    }
+    if (lane == 0) {
+      int jj = j0;
+      do {
+        int j1 = S.way[jj];
+        S.p[jj] = S.p[j1];
+        jj = j1;
+      } while (jj);
+    }
+    __syncthreads();
+  }
+  if (lane < m && S.p[lane + 1] != 0) row2col[S.p[lane + 1] - 1] = lane;
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// one OCSort.update() for one clip, executed by one wavefront
+// ------------------------------------------------------------------------------------------
+struct StepShared {
+  double det[MAXD][6];
+  double tbox[MAXT][4];
+  double iou[MAXD][MAXT];
+  double cost[MAXD][MAXT];
+  int d2t[MAXD];      // detection -> tracker position (or -1)
+  int r2c[MAXT];      // assignment scratch
+  int um_d[MAXD];     // unmatched detections, in the reference's list order
+  int um_t[MAXT];
+  int n_um_d, n_um_t, flag;
+  LapShared lap;
+};
+
+__device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& sh, int nd, double time, const TrackParams& p,
+                            double q44, double q66, int lane) {
+  if (lane == 0) st.frame_count += 1;
+  int T = st.ntrk;
+  // ---- predict (KalmanBoxTracker.predict) ----
+  bool isnan_box = false;
+  if (lane < T) {
+    Trk& k = st.trk[st.order[lane]];
+    if ((k.x[6] + k.x[2]) <= 0.0) k.x[6] *= 0.0;
+    kf_predict(k, q44, q66);
+    k.age += 1;
+    if (k.time_since_update > 0) k.hit_streak = 0;
+    k.time_since_update += 1;
+    double bx[4];
+    x_to_bbox(k.x, bx);
+    isnan_box = (bx[0] != bx[0]) || (bx[1] != bx[1]) || (bx[2] != bx[2]) || (bx[3] != bx[3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) sh.tbox[lane][i] = bx[i];
+  }
+  unsigned long long nanmask = __ballot(isnan_box);
+  if (nanmask) {  // drop trackers whose predicted box is NaN (stable compaction)
+    unsigned long long keep = ~nanmask & (T >= 64 ? ~0ull : ((1ull << T) - 1ull));
+    int slot = lane < T ? st.order[lane] : 0;
+    double bx[4] = {0, 0, 0, 0};
+    if (lane < T)
+      for (int i = 0; i < 4; i++) bx[i] = sh.tbox[lane][i];
+    __syncthreads();
+    if (lane < T) {
+      if (isnan_box) atomicAnd(&st.used, ~(1ull << slot));
+      else {
+        int np_ = __popcll(keep & ((1ull << lane) - 1ull));
+        st.order[np_] = slot;
+        for (int i = 0; i < 4; i++) sh.tbox[np_][i] = bx[i];
+      }
+    }
+    T = __popcll(keep);
+    if (lane == 0) st.ntrk = T;
+  }
+  __syncthreads();
+  const int slot = lane < T ? st.order[lane] : 0;
+  // ---- first association: IoU + velocity-direction consistency ----
+  int colsum = 0;
+  if (lane < T) {
+    Trk& k = st.trk[slot];
+    const double* pobs = nullptr;  // k_previous_obs
+    if (k.has_obs) {
+      for (int i = 0; i < p.delta_t; i++) {
+        int a = k.age - (p.delta_t - i);
+        if (a >= 0 && k.obs_age[a & 3] == a) { pobs = k.obs[a & 3]; break; }
+      }
+      if (!pobs) pobs = k.last_obs;
+    }
+    double pcx = -1.0, pcy = -1.0, valid = 0.0;
+    if (pobs) { pcx = (pobs[0] + pobs[2]) / 2.0; pcy = (pobs[1] + pobs[3]) / 2.0; valid = pobs[4] < 0.0 ? 0.0 : 1.0; }
+    double vy = k.has_vel ? k.vel[0] : 0.0, vx = k.has_vel ? k.vel[1] : 0.0;
+    const double PI = 3.141592653589793;
+    for (int d = 0; d < nd; d++) {
+      const double* dt = sh.det[d];
+      double io = iou_xyxy(dt, sh.tbox[lane]);
+      double dx = (dt[0] + dt[2]) / 2.0 - pcx, dy = (dt[1] + dt[3]) / 2.0 - pcy;
+      double norm = sqrt(dx * dx + dy * dy) + 1e-6;
+      double X = dx / norm, Y = dy / norm;
+      double c = vx * X + vy * Y;
+      c = fmin(fmax(c, -1.0), 1.0);
+      double ang = (PI / 2.0 - fabs(acos(c))) / PI;
+      double ac = ((valid * ang) * p.inertia) * dt[4];
+      sh.iou[d][lane] = io;
+      sh.cost[d][lane] = -(io + ac);
+      colsum += io > p.iou_thr ? 1 : 0;
+    }
+  }
+  if (lane < MAXD) sh.d2t[lane] = -1;
+  __syncthreads();
+  int maxcol = colsum;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) maxcol = max(maxcol, __shfl_xor(maxcol, o));
+  int maxrow = 0;
+  for (int d = 0; d < nd; d++) {
+    unsigned long long m = __ballot(lane < T && sh.iou[d][lane] > p.iou_thr);
+    maxrow = max(maxrow, __popcll(m));
+  }
+  int my_det = -1;  // detection matched to this lane's tracker
+  if (nd > 0 && T > 0) {
+    if (maxrow == 1 && maxcol == 1) {
+      if (lane < T)
+        for (int d = 0; d < nd; d++)
+          if (sh.iou[d][lane] > p.iou_thr) my_det = d;
+    } else {
+      if (nd <= T) {
+        lap_solve(&sh.cost[0][0], MAXT, false, nd, T, sh.r2c, sh.lap, lane);
+        if (lane < T)
+          for (int d = 0; d < nd; d++)
+            if (sh.r2c[d] == lane) my_det = d;
+      } else {
+        lap_solve(&sh.cost[0][0], MAXT, true, T, nd, sh.r2c, sh.lap, lane);
+        if (lane < T) my_det = sh.r2c[lane];
+      }
+    }
+  }
+  bool rejected = false;  // assigned but IoU below the threshold
+  if (lane < T && my_det >= 0) {
+    if (sh.iou[my_det][lane] < p.iou_thr) { rejected = true; sh.d2t[my_det] = -2; my_det = -1; }
+    else sh.d2t[my_det] = lane;
+  }
+  __syncthreads();
+  if (lane < T && my_det >= 0) trk_update(st.trk[slot], sh.det[my_det], q44, q66, p.delta_t);
+  // unmatched lists in the reference's order: never-assigned ascending, then rejected ascending
+  if (lane == 0) {
+    int n = 0;
+    for (int d = 0; d < nd; d++) if (sh.d2t[d] == -1) sh.um_d[n++] = d;
+    for (int d = 0; d < nd; d++) if (sh.d2t[d] == -2) sh.um_d[n++] = d;
+    sh.n_um_d = n;
+  }
+  {
+    bool unm = lane < T && my_det < 0;
+    unsigned long long m = __ballot(unm);
+    if (unm) sh.um_t[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+    if (lane == 0) sh.n_um_t = __popcll(m);
+  }
+  __syncthreads();
+  // ---- observation-centric recovery (second association on the last observations) ----
+  int nud = sh.n_um_d, nut = sh.n_um_t;
+  bool recovered = false;
+  if (nud > 0 && nut > 0) {
+    double mx = -1e300;
+    if (lane < nut) {
+      const Trk& k = st.trk[st.order[sh.um_t[lane]]];
+      double lb[4];
+      for (int i = 0; i < 4; i++) lb[i] = k.last_obs[i];
+      for (int i = 0; i < nud; i++) {
+        const double* dt = sh.det[sh.um_d[i]];
+        double v = p.asso == 1 ? diou_xyxy(dt, lb) : iou_xyxy(dt, lb);
+        sh.iou[i][lane] = v;
+        sh.cost[i][lane] = -v;
+        mx = fmax(mx, v);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    __syncthreads();
+    if (mx > p.iou_thr) {
+      int mine = -1;  // index into um_d matched to um_t[lane]
+      if (nud <= nut) {
+        lap_solve(&sh.cost[0][0], MAXT, false, nud, nut, sh.r2c, sh.lap, lane);
+        if (lane < nut)
+          for (int i = 0; i < nud; i++)
+            if (sh.r2c[i] == lane) mine = i;
+      } else {
+        lap_solve(&sh.cost[0][0], MAXT, true, nut, nud, sh.r2c, sh.lap, lane);
+        if (lane < nut) mine = sh.r2c[lane];
+      }
+      if (lane < nut && mine >= 0 && !(sh.iou[mine][lane] < p.iou_thr)) {
+        int tp = sh.um_t[lane];
+        trk_update(st.trk[st.order[tp]], sh.det[sh.um_d[mine]], q44, q66, p.delta_t);
+        sh.d2t[sh.um_d[mine]] = tp;
+        sh.um_t[lane] = -1;
+      }
+      recovered = true;
+      __syncthreads();
+      if (lane == 0) {  // np.setdiff1d: sorted ascending
+        int n = 0;
+        for (int d = 0; d < nd; d++) if (sh.d2t[d] < 0) sh.um_d[n++] = d;
+        sh.n_um_d = n;
+      }
+      __syncthreads();
+    }
+  }
+  (void)recovered;
+  // ---- unmatched trackers: update(None) ----
+  if (lane < nut && sh.um_t[lane] >= 0) trk_update(st.trk[st.order[sh.um_t[lane]]], nullptr, q44, q66, p.delta_t);
+  __syncthreads();
+  // ---- births ----
+  nud = sh.n_um_d;
+  if (lane == 0) {
+    for (int i = 0; i < nud; i++) {
+      if (st.ntrk >= MAXT) { st.overflow += 1; continue; }
+      int s = __ffsll((long long)~st.used) - 1;
+      st.used |= 1ull << s;
+      Trk& k = st.trk[s];
+      const double* dt = sh.det[sh.um_d[i]];
+      double z[4];
+      bbox_to_z(dt, z);
+      for (int j = 0; j < 7; j++) k.x[j] = j < 4 ? z[j] : 0.0;
+      for (int b = 0; b < 3; b++) { k.B[b][0] = 10.0; k.B[b][1] = 0.0; k.B[b][2] = 0.0; k.B[b][3] = 10000.0; }
+      k.Pr = 10.0;
+      k.has_saved = 0; k.observed = 0; k.gap = 0; k.has_obs = 0; k.has_vel = 0;
+      for (int j = 0; j < 5; j++) k.last_obs[j] = -1.0;
+      for (int j = 0; j < 4; j++) { k.obs_age[j] = -1; k.last_z[j] = 0.0; }
+      k.vel[0] = k.vel[1] = 0.0;
+      k.time_since_update = 0; k.hits = 0; k.hit_streak = 0; k.age = 0; k.nrows = 0;
+      k.cum = 0.0; k.cum_c = 0.0; k.prev_x = 0.0; k.prev_y = 0.0;
+      k.conf = dt[4]; k.cls = dt[5];
+      k.id = st.next_id++;
+      st.order[st.ntrk++] = s;
+    }
+  }
+  __syncthreads();
+  // ---- emission (reverse list order) + deletion ----
+  T = st.ntrk;
+  bool emit = false, keep = true;
+  int myslot = 0;
+  if (lane < T) {
+    myslot = st.order[lane];
+    const Trk& k = st.trk[myslot];
+    emit = k.time_since_update < 1 && (k.hit_streak >= p.min_hits || st.frame_count <= p.min_hits);
+    keep = !(k.time_since_update > p.max_age);
+  }
+  unsigned long long em = __ballot(emit);
+  const int nem = __popcll(em);
+  const int base = st.nrows;
+  if (emit) {
+    Trk& k = st.trk[myslot];
+    int ridx = lane >= 63 ? 0 : __popcll(em >> (lane + 1));  // rows of later trackers come first
+    double bx[4];
+    if (obs_sum_negative(k)) x_to_bbox(k.x, bx);
+    else { bx[0] = k.last_obs[0]; bx[1] = k.last_obs[1]; bx[2] = k.last_obs[2]; bx[3] = k.last_obs[3]; }
+    double xc = (bx[0] + bx[2]) / 2.0, yc = (bx[1] + bx[3]) / 2.0;
+    if (ridx < MAXD) {
+      double* lo = st.last_out[ridx];
+      lo[0] = bx[0]; lo[1] = bx[1]; lo[2] = bx[2]; lo[3] = bx[3];
+      lo[4] = (double)(k.id + 1); lo[5] = k.cls; lo[6] = k.conf; lo[7] = k.x[4]; lo[8] = k.x[5];
+    }
+    if (base + ridx < rows_cap) {
+      Row r;
+      r.id = k.id + 1; r.time = time; r.x = xc; r.y = yc; r.dx = k.x[4]; r.dy = k.x[5];
+      r.h = fabs(bx[3] - bx[1]); r.w = fabs(bx[2] - bx[0]);
+      rows[base + ridx] = r;
+    }
+    // running path length of this id (reference track.py:109-113: sqrt(dx^2+dy^2), cumulative per id)
+    if (k.nrows > 0) {
+      double ex = xc - k.prev_x, ey = yc - k.prev_y;
+      double dist = sqrt(ex * ex + ey * ey);
+      double yk = dist - k.cum_c;
+      double tk = k.cum + yk;
+      k.cum_c = (tk - k.cum) - yk;
+      k.cum = tk;
+    }
+    k.prev_x = xc; k.prev_y = yc; k.nrows += 1;
+  }
+  if (lane == 0) {
+    st.last_n = min(nem, MAXD);
+    if (base + nem > rows_cap) { st.rows_overflow += base + nem - rows_cap; st.nrows = rows_cap; }
+    else st.nrows = base + nem;
+  }
+  unsigned long long km = __ballot(lane < T && keep);
+  if (km != (T >= 64 ? ~0ull : ((1ull << T) - 1ull))) {
+    __syncthreads();
+    if (lane < T) {
+      if (keep) st.order[__popcll(km & ((1ull << lane) - 1ull))] = myslot;
+      else {
+        atomicAnd(&st.used, ~(1ull << myslot));
+      }
+    }
+    // a finished track competes for the export id (max cumulative distance; ties -> lower id);
+    // the few deaths of a frame are serialised
+    unsigned long long dead = ~km & (T >= 64 ? ~0ull : ((1ull << T) - 1ull));
+    while (dead) {
+      int l = __ffsll((long long)dead) - 1;
+      dead &= dead - 1;
+      if (lane == l) {
+        const Trk& k = st.trk[myslot];
+        if (k.nrows >= 2 && (k.cum > st.best_cum || (k.cum == st.best_cum && k.id + 1 < st.best_id))) { st.best_cum = k.cum; st.best_id = k.id + 1; }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) st.ntrk = __popcll(km);
+  }
+  __syncthreads();
+}
+
+// Frames come either as double detections (host-provided, OCSort.update call shape) ...
+__global__ __launch_bounds__(64) void tracker_kernel(ClipState* states, Row* rows, int rows_cap, const double* dets,
+                                                     const int* counts, const double* times, int F, int nclips, TrackParams p,
+                                                     double q44, double q66) {
+  __shared__ StepShared sh;
+  const int clip = blockIdx.x, lane = threadIdx.x;
+  ClipState& st = states[clip];
+  Row* myrows = rows + (size_t)clip * rows_cap;
+  for (int f = 0; f < F; f++) {
+    const int n = counts[(size_t)f * nclips + clip];
+    if (n <= 0) continue;  // reference track.py:180-181: the tracker is not stepped on empty frames
+    const double* d = dets + ((size_t)f * nclips + clip) * MAXD * 6;
+    __syncthreads();
+    if (lane == 0) {  // dets = dets[confs > det_thresh]
+      int m = 0;
+      for (int i = 0; i < n && i < MAXD; i++)
+        if (d[i * 6 + 4] > p.det_thresh) { for (int j = 0; j < 6; j++) sh.det[m][j] = d[i * 6 + j]; m++; }
+      sh.flag = m;
+    }
+    __syncthreads();
+    ocsort_step(st, myrows, rows_cap, sh, sh.flag, times[(size_t)f * nclips + clip], p, q44, q66, lane);
+  }
+}
+
+// ... or straight from the detector's device outputs (fused pipeline): applies the detection
+// threshold of reference odt.py:70-75 and the reorder of odt.py:102-118.
+__global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states, Row* rows, int rows_cap, const float* boxes,
+                                                              const float* scores, const int* counts, const double* times,
+                                                              int nclips, float det_threshold, TrackParams p, double q44, double q66) {
+  __shared__ StepShared sh;
+  const int clip = blockIdx.x, lane = threadIdx.x;
+  ClipState& st = states[clip];
+  if (lane == 0) {
+    int n = counts[clip], m = 0, mk = 0;
+    for (int i = 0; i < n && i < MAXD; i++) {
+      float s = scores[clip * MAXD + i];
+      if (s >= det_threshold) {
+        mk++;
+        if ((double)s > p.det_thresh) {
+          const float* b = boxes + ((size_t)clip * MAXD + i) * 4;  // ymin,xmin,ymax,xmax
+          sh.det[m][0] = (double)b[1]; sh.det[m][1] = (double)b[0]; sh.det[m][2] = (double)b[3]; sh.det[m][3] = (double)b[2];
+          sh.det[m][4] = (double)s; sh.det[m][5] = 0.0;
+          m++;
+        }
+      }
+    }
+    sh.flag = mk > 0 ? m : -1;
+  }
+  __syncthreads();
+  if (sh.flag < 0) return;
+  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, sh.flag, times[clip], p, q44, q66, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// export id selection + rep analysis
+// ------------------------------------------------------------------------------------------
+struct RollMean {  // pandas roll_mean state (Kahan add / remove)
+  double sum, c_add, c_rem, prev;
+  long nobs, neg, same;
+  __device__ void init() { sum = 0; c_add = 0; c_rem = 0; prev = __builtin_nan(""); nobs = 0; neg = 0; same = 0; }
+  __device__ void add(double v) {
+    nobs += 1;
+    double y = v - c_add;
+    double t = sum + y;
+    c_add = (t - sum) - y;
+    sum = t;
+    if (__builtin_signbit(v)) neg += 1;
+    if (v == prev) same += 1; else same = 1;
+    prev = v;
+  }
+  __device__ void remove(double v) {
+    nobs -= 1;
+    double y = -v - c_rem;
+    double t = sum + y;
+    c_rem = (t - sum) - y;
+    sum = t;
+    if (__builtin_signbit(v)) neg -= 1;
+  }
+  __device__ double mean() const {
+    double r = sum / (double)nobs;
+    if (same >= nobs) r = prev;
+    else if (neg == 0 && r < 0) r = 0.0;
+    else if (neg == nobs && r > 0) r = 0.0;
+    return r;
+  }
+};
+
+struct VtParams {
+  double plate_diameter, diff_threshold, min_distance;
+  int preprocess, flush;
+};
+
+struct VtState {  // reference VelocityTracker.py:30-48
+  int phase, neg, pos, nph, n, has_prev, has_max;
+  double y_prev, max_y_diff;
+  // the single RunningAverage(30) fed width then height (VelocityTracker.py:44-45,98-99)
+  double win[30];
+  int whead, wcount;
+  double wtotal;
+};
+
+__device__ inline double ra_update(VtState& s, double v) {  // reference RunningAverage.py:16-27
+  s.win[(s.whead + s.wcount) % 30] = v;
+  s.wcount += 1;
+  s.wtotal += v;
+  if (s.wcount >= 30) {
+    double avg = s.wtotal / 30.0;
+    s.wtotal -= s.win[s.whead];
+    s.whead = (s.whead + 1) % 30;
+    s.wcount -= 1;
+    return avg;
+  }
+  return s.wtotal / (double)s.wcount;
+}
+
+__device__ inline void vt_filter(VtState& s, double* ph) {  // VelocityTracker.py:50-67
+  double thr = s.max_y_diff / 2;
+  int o = 0;
+  for (int i = 0; i < s.nph; i++) {
+    double yd = fabs(ph[i * 6 + 2] - ph[i * 6 + 3]);
+    if (!(yd < thr)) {
+      if (o != i) for (int j = 0; j < 6; j++) ph[o * 6 + j] = ph[i * 6 + j];
+      o++;
+    }
+  }
+  s.nph = o;
+}
+
+__device__ inline void vt_end_phase(VtState& s, const VtParams& p, const double* xs, const double* ys, const double* ws,
+                                    const double* hs, const double* ts, double* ph) {  // VelocityTracker.py:171-222
+  int imax = 0, imin = 0;
+  for (int i = 1; i < s.n; i++) {
+    if (ys[i] > ys[imax]) imax = i;
+    if (ys[i] < ys[imin]) imin = i;
+  }
+  int st = s.phase == 0 ? imax : imin, en = s.phase == 0 ? imin : imax;
+  double y_diff = fabs(ys[st] - ys[en]);
+  if (!s.has_max || y_diff > s.max_y_diff) {
+    s.max_y_diff = y_diff;
+    s.has_max = 1;
+    vt_filter(s, ph);
+  }
+  if (y_diff > s.max_y_diff * p.diff_threshold) {
+    double distance = 0.0;
+    for (int i = st + 1; i < en + 1; i++) {
+      double ddx = fabs(xs[i] - xs[i - 1]) / ((ws[i] + ws[i - 1]) / 2) * p.plate_diameter;
+      double ddy = fabs(ys[i] - ys[i - 1]) / ((hs[i] + hs[i - 1]) / 2) * p.plate_diameter;
+      distance += ddx + ddy;
+    }
+    if (distance < p.min_distance) {
+      s.neg = 0; s.pos = 0; s.phase = 2;
+      return;
+    }
+    if (s.nph < MAXPH) {
+      double* o = ph + s.nph * 6;
+      o[0] = ts[st]; o[1] = ts[en]; o[2] = ys[st]; o[3] = ys[en]; o[4] = distance; o[5] = (double)s.phase;
+      s.nph += 1;
+    }
+    vt_filter(s, ph);
+  }
+  s.phase = 2;
+  s.pos = 0; s.neg = 0;
+}
+
+// cols: [T][7] = time,x,y,dx,dy,h,w of ONE track.  One lane per clip does the sequential scan.
+__device__ void analyze_track(const double* cols, int T, const VtParams& p, double* scratch /*5*T*/, double* ph, int* nph_out) {
+  double* xs = scratch; double* ys = xs + T; double* ws = ys + T; double* hs = ws + T; double* ts = hs + T;
+  VtState s;
+  s.phase = 2; s.neg = 0; s.pos = 0; s.nph = 0; s.n = 0; s.has_prev = 0; s.has_max = 0; s.y_prev = 0; s.max_y_diff = 0;
+  s.whead = 0; s.wcount = 0; s.wtotal = 0.0;
+  RollMean rx, ry, rh, rw;
+  rx.init(); ry.init(); rh.init(); rw.init();
+  for (int i = 0; i < T; i++) {
+    const double* r = cols + (size_t)i * 7;
+    double time = r[0], x = r[1], y = r[2], h = r[5], w = r[6];
+    if (p.preprocess) {  // plot.py:90-95 (dx, dy columns are smoothed there too but never used downstream)
+      if (i >= 5) { rx.remove(cols[(size_t)(i - 5) * 7 + 1]); ry.remove(cols[(size_t)(i - 5) * 7 + 2]); }
+      rx.add(x); ry.add(y); rh.add(h); rw.add(w);
+      x = rx.mean(); y = ry.mean(); h = rh.mean(); w = rw.mean();
+    }
+    // VelocityTracker.process_measurements (VelocityTracker.py:92-158)
+    double width = ra_update(s, w);
+    double height = ra_update(s, h);
+    double dy = r[4];
+    if (s.has_prev) dy = y - s.y_prev;
+    else if (p.preprocess) dy = r[4];  // first sample: the (smoothed == raw) incoming dy
+    if (s.phase != 2) { xs[s.n] = x; ys[s.n] = y; ws[s.n] = width; hs[s.n] = height; ts[s.n] = time; s.n++; }
+    if (s.phase == 0) {
+      if (dy > 0) { s.pos += 1; s.neg = 0; if (s.pos >= 1) vt_end_phase(s, p, xs, ys, ws, hs, ts, ph); }
+      else s.pos = 0;
+    }
+    if (s.phase == 1) {
+      if (dy < 0) { s.neg += 1; s.pos = 0; if (s.neg >= 1) vt_end_phase(s, p, xs, ys, ws, hs, ts, ph); }
+      else { s.neg = 0; s.pos += 1; }
+    }
+    if (dy < 0 && s.phase == 2) {
+      s.neg += 1; s.pos = 0;
+      if (s.neg == 1) s.n = 0;
+      else { xs[s.n] = x; ys[s.n] = y; ws[s.n] = width; hs[s.n] = height; ts[s.n] = time; s.n++; }
+      if (s.neg >= 3) { s.phase = 0; s.pos = 0; s.neg = 0; }
+    }
+    if (dy > 0 && s.phase == 2) {
+      s.pos += 1; s.neg = 0;
+      if (s.pos == 1) s.n = 0;
+      else { xs[s.n] = x; ys[s.n] = y; ws[s.n] = width; hs[s.n] = height; ts[s.n] = time; s.n++; }
+      if (s.pos >= 3) { s.phase = 1; s.pos = 0; s.neg = 0; }
+    }
+    s.y_prev = y; s.has_prev = 1;
+  }
+  if (p.flush && s.phase != 2) vt_end_phase(s, p, xs, ys, ws, hs, ts, ph);  // end_processing, VelocityTracker.py:224-230
+  *nph_out = s.nph;
+}
+
+__global__ __launch_bounds__(64) void analyze_kernel(const double* cols, const int* T, int stride_rows, VtParams p, double* scratch,
+                                                     double* phases, int* nph) {
+  const int clip = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  analyze_track(cols + (size_t)clip * stride_rows * 7, T[clip], p, scratch + (size_t)clip * stride_rows * 5,
+                phases + (size_t)clip * MAXPH * 6, nph + clip);
+}
+
+// end of clip: live tracks compete for the export id too; then gather the rows of the winner.
+__global__ __launch_bounds__(64) void select_gather_kernel(ClipState* states, const Row* rows, int rows_cap, double* cols, int* T,
+                                                           int* best_ids) {
+  const int clip = blockIdx.x, lane = threadIdx.x;
+  ClipState& st = states[clip];
+  __shared__ int s_best;
+  if (lane == 0) {
+    double bc = st.best_cum;
+    int bi = st.best_id;
+    for (int t = 0; t < st.ntrk; t++) {
+      const Trk& k = st.trk[st.order[t]];
+      if (k.nrows >= 2 && (k.cum > bc || (k.cum == bc && (bi < 0 || k.id + 1 < bi)))) { bc = k.cum; bi = k.id + 1; }
+    }
+    s_best = bi;
+    best_ids[clip] = bi;
+  }
+  __syncthreads();
+  const int best = s_best;
+  const Row* r = rows + (size_t)clip * rows_cap;
+  double* c = cols + (size_t)clip * rows_cap * 7;
+  const int n = st.nrows;
+  int outn = 0;  // stable, ordered gather with ballots
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool hit = i < n && best >= 0 && r[i].id == best;
+    unsigned long long m = __ballot(hit);
+    if (hit) {
+      double* o = c + (size_t)(outn + __popcll(m & ((1ull << lane) - 1ull))) * 7;
+      o[0] = r[i].time; o[1] = r[i].x; o[2] = r[i].y; o[3] = r[i].dx; o[4] = r[i].dy; o[5] = r[i].h; o[6] = r[i].w;
+    }
+    outn += __popcll(m);
+  }
+  if (lane == 0) T[clip] = outn;
+}
+
+__global__ void init_states_kernel(ClipState* states, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ClipState& st = states[i];
+  st.ntrk = 0; st.frame_count = 0; st.next_id = 0; st.overflow = 0; st.nrows = 0; st.rows_overflow = 0;
+  st.best_id = -1; st.last_n = 0; st.best_cum = -1.0; st.used = 0ull;
+}
+
+}  // namespace vbt
+
+using namespace vbt;
+
+struct vbt_tracker {
+  int n_clips = 0, rows_cap = 0, device = 0;
+  TrackParams p;
+  double q44 = 0, q66 = 0;
+  ClipState* states = nullptr;
+  Row* rows = nullptr;
+  double* cols = nullptr;     // [n_clips][rows_cap][7] gathered rows of the export id
+  double* scratch = nullptr;  // [n_clips][rows_cap][5]
+  double* phases = nullptr;   // [n_clips][MAXPH][6]
+  int* nph = nullptr;
+  int* T = nullptr;
+  int* best = nullptr;
+  double* d_times = nullptr;  // [n_clips]
+  bool finished = false;
+};
+
+extern "C" {
+
+int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* prm, int device, vbt_tracker** out) {
+  if (!out || !prm || n_clips < 1 || rows_cap < 1) { set_error("vbt_tracker_create: bad argument"); return VBT_ERR_ARG; }
+  if (prm->delta_t < 1 || prm->delta_t > 3) { set_error("delta_t must be 1..3"); return VBT_ERR_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_error("vbt_tracker_create: HIP device %d not available (%d visible) - no CPU fallback", device, ndev);
+    return VBT_ERR_HIP;
+  }
+  VBT_HIP_CHECK(hipSetDevice(device));
+  vbt_tracker* t = new vbt_tracker();
+  t->n_clips = n_clips; t->rows_cap = rows_cap; t->device = device;
+  t->p.max_age = prm->max_age; t->p.min_hits = prm->min_hits; t->p.delta_t = prm->delta_t; t->p.asso = prm->asso;
+  t->p.iou_thr = prm->iou_threshold; t->p.inertia = prm->inertia; t->p.det_thresh = prm->det_thresh;
+  // Q = eye(7); Q[-1,-1] *= 0.01; Q[4:,4:] *= 0.01
+  double q = 1.0;
+  q *= 0.01;
+  t->q44 = q;
+  double q6 = 1.0;
+  q6 *= 0.01;
+  q6 *= 0.01;
+  t->q66 = q6;
+  auto fail = [&](const char* what) { set_error("hipMalloc failed for %s", what); vbt_tracker_destroy(t); return VBT_ERR_HIP; };
+  if (hipMalloc((void**)&t->states, sizeof(ClipState) * n_clips) != hipSuccess) return fail("tracker state");
+  if (hipMalloc((void**)&t->rows, sizeof(Row) * (size_t)n_clips * rows_cap) != hipSuccess) return fail("rows");
+  if (hipMalloc((void**)&t->cols, sizeof(double) * 7 * (size_t)n_clips * rows_cap) != hipSuccess) return fail("cols");
+  if (hipMalloc((void**)&t->scratch, sizeof(double) * 5 * (size_t)n_clips * rows_cap) != hipSuccess) return fail("scratch");
+  if (hipMalloc((void**)&t->phases, sizeof(double) * 6 * MAXPH * (size_t)n_clips) != hipSuccess) return fail("phases");
+  if (hipMalloc((void**)&t->nph, sizeof(int) * n_clips) != hipSuccess) return fail("nph");
+  if (hipMalloc((void**)&t->T, sizeof(int) * n_clips) != hipSuccess) return fail("T");
+  if (hipMalloc((void**)&t->best, sizeof(int) * n_clips) != hipSuccess) return fail("best");
+  if (hipMalloc((void**)&t->d_times, sizeof(double) * n_clips) != hipSuccess) return fail("times");
+  init_states_kernel<<<(n_clips + 63) / 64, 64>>>(t->states, n_clips);
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  *out = t;
+  return VBT_OK;
+}
+
+void vbt_tracker_destroy(vbt_tracker* t) {
+  if (!t) return;
+  (void)hipFree(t->states); (void)hipFree(t->rows); (void)hipFree(t->cols); (void)hipFree(t->scratch);
+  (void)hipFree(t->phases); (void)hipFree(t->nph); (void)hipFree(t->T); (void)hipFree(t->best); (void)hipFree(t->d_times);
+  delete t;
+}
+
+int vbt_tracker_reset(vbt_tracker* t) {
+  if (!t) { set_error("NULL tracker"); return VBT_ERR_ARG; }
+  init_states_kernel<<<(t->n_clips + 63) / 64, 64>>>(t->states, t->n_clips);
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  t->finished = false;
+  return VBT_OK;
+}
+
+int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts, const double* times, int F) {
+  if (!t || !dets || !counts || !times || F < 1) { set_error("vbt_tracker_update: bad argument"); return VBT_ERR_ARG; }
+  VBT_HIP_CHECK(hipSetDevice(t->device));
+  size_t nd = (size_t)F * t->n_clips;
+  double* dd = nullptr; int* dc = nullptr; double* dt = nullptr;
+  VBT_HIP_CHECK(hipMalloc((void**)&dd, nd * MAXD * 6 * sizeof(double)));
+  VBT_HIP_CHECK(hipMalloc((void**)&dc, nd * sizeof(int)));
+  VBT_HIP_CHECK(hipMalloc((void**)&dt, nd * sizeof(double)));
+  VBT_HIP_CHECK(hipMemcpy(dd, dets, nd * MAXD * 6 * sizeof(double), hipMemcpyHostToDevice));
+  VBT_HIP_CHECK(hipMemcpy(dc, counts, nd * sizeof(int), hipMemcpyHostToDevice));
+  VBT_HIP_CHECK(hipMemcpy(dt, times, nd * sizeof(double), hipMemcpyHostToDevice));
+  tracker_kernel<<<t->n_clips, 64>>>(t->states, t->rows, t->rows_cap, dd, dc, dt, F, t->n_clips, t->p, t->q44, t->q66);
+  hipError_t e = hipDeviceSynchronize();
+  (void)hipFree(dd); (void)hipFree(dc); (void)hipFree(dt);
+  if (e != hipSuccess) { set_error("tracker kernel failed: %s", hipGetErrorString(e)); return VBT_ERR_HIP; }
+  t->finished = false;
+  return VBT_OK;
+}
+
+int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
+                                       const double* times_host, float det_threshold, void* stream) {
+  if (!t || !boxes_dev || !scores_dev || !counts_dev || !times_host) { set_error("bad argument"); return VBT_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  VBT_HIP_CHECK(hipMemcpyAsync(t->d_times, times_host, sizeof(double) * t->n_clips, hipMemcpyHostToDevice, st));
+  tracker_from_det_kernel<<<t->n_clips, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, t->d_times,
+                                                     t->n_clips, det_threshold, t->p, t->q44, t->q66);
+  VBT_HIP_CHECK(hipGetLastError());
+  t->finished = false;
+  return VBT_OK;
+}
+
+static int fetch_state_header(vbt_tracker* t, int clip, ClipState* hdr_only) {
+  // copies only the leading scalars + order + used (not the tracker array)
+  VBT_HIP_CHECK(hipMemcpy(hdr_only, &t->states[clip], offsetof(ClipState, last_out), hipMemcpyDeviceToHost));
+  return VBT_OK;
+}
+
+int vbt_tracker_last_output(vbt_tracker* t, int clip, double* out7, double* vel2, int cap, int* M) {
+  if (!t || !out7 || !vel2 || !M || clip < 0 || clip >= t->n_clips) { set_error("bad argument"); return VBT_ERR_ARG; }
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<char> buf(offsetof(ClipState, trk));
+  VBT_HIP_CHECK(hipMemcpy(buf.data(), &t->states[clip], buf.size(), hipMemcpyDeviceToHost));
+  const ClipState* st = (const ClipState*)buf.data();
+  int n = std::min(st->last_n, cap);
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < 7; j++) out7[i * 7 + j] = st->last_out[i][j];
+    vel2[i * 2] = st->last_out[i][7];
+    vel2[i * 2 + 1] = st->last_out[i][8];
+  }
+  *M = n;
+  return VBT_OK;
+}
+
+int vbt_tracker_status(vbt_tracker* t, int clip, int32_t* n_rows, int32_t* n_trackers, int32_t* overflow, int32_t* rows_overflow,
+                       int32_t* frame_count) {
+  if (!t || clip < 0 || clip >= t->n_clips) { set_error("bad argument"); return VBT_ERR_ARG; }
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<char> buf(offsetof(ClipState, last_out));
+  ClipState* st = (ClipState*)buf.data();
+  int rc = fetch_state_header(t, clip, st);
+  if (rc) return rc;
+  if (n_rows) *n_rows = st->nrows;
+  if (n_trackers) *n_trackers = st->ntrk;
+  if (overflow) *overflow = st->overflow;
+  if (rows_overflow) *rows_overflow = st->rows_overflow;
+  if (frame_count) *frame_count = st->frame_count;
+  return VBT_OK;
+}
+
+int vbt_tracker_get_trackers(vbt_tracker* t, int clip, int32_t* ids, double* kfx, int cap, int* n) {
+  if (!t || !ids || !kfx || !n || clip < 0 || clip >= t->n_clips) { set_error("bad argument"); return VBT_ERR_ARG; }
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<char> buf(sizeof(ClipState));
+  VBT_HIP_CHECK(hipMemcpy(buf.data(), &t->states[clip], sizeof(ClipState), hipMemcpyDeviceToHost));
+  const ClipState* st = (const ClipState*)buf.data();
+  int m = std::min(st->ntrk, cap);
+  for (int i = 0; i < m; i++) {
+    const Trk& k = st->trk[st->order[i]];
+    ids[i] = k.id;
+    for (int j = 0; j < 7; j++) kfx[i * 7 + j] = k.x[j];
+  }
+  *n = m;
+  return VBT_OK;
+}
+
+int vbt_tracker_rows(vbt_tracker* t, int clip, int64_t* id, double* cols7, int cap, int* n) {
+  if (!t || !id || !cols7 || !n || clip < 0 || clip >= t->n_clips) { set_error("bad argument"); return VBT_ERR_ARG; }
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  std::vector<char> hb(offsetof(ClipState, last_out));
+  ClipState* st = (ClipState*)hb.data();
+  int rc = fetch_state_header(t, clip, st);
+  if (rc) return rc;
+  if (st->overflow > 0) { set_error("clip %d: more than %d live tracks (%d births dropped)", clip, MAXT, st->overflow); return VBT_ERR_CAPACITY; }
+  if (st->rows_overflow > 0) { set_error("clip %d: row capacity %d exceeded by %d", clip, t->rows_cap, st->rows_overflow); return VBT_ERR_CAPACITY; }
+  int m = st->nrows;
+  if (m > cap) { set_error("clip %d has %d rows, buffer holds %d", clip, m, cap); return VBT_ERR_CAPACITY; }
+  std::vector<Row> r(m);
+  if (m) VBT_HIP_CHECK(hipMemcpy(r.data(), t->rows + (size_t)clip * t->rows_cap, sizeof(Row) * m, hipMemcpyDeviceToHost));
+  for (int i = 0; i < m; i++) {
+    id[i] = r[i].id;
+    double* o = cols7 + (size_t)i * 7;
+    o[0] = r[i].time; o[1] = r[i].x; o[2] = r[i].y; o[3] = r[i].dx; o[4] = r[i].dy; o[5] = r[i].h; o[6] = r[i].w;
+  }
+  *n = m;
+  return VBT_OK;
+}
+
+int vbt_tracker_finish(vbt_tracker* t, double plate_diameter, double diff_threshold, double min_distance, void* stream) {
+  if (!t) { set_error("NULL tracker"); return VBT_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  select_gather_kernel<<<t->n_clips, 64, 0, st>>>(t->states, t->rows, t->rows_cap, t->cols, t->T, t->best);
+  VtParams vp{plate_diameter, diff_threshold, min_distance, 1, 1};
+  analyze_kernel<<<t->n_clips, 64, 0, st>>>(t->cols, t->T, t->rows_cap, vp, t->scratch, t->phases, t->nph);
+  VBT_HIP_CHECK(hipGetLastError());
+  t->finished = true;
+  return VBT_OK;
+}
+
+int vbt_tracker_phases(vbt_tracker* t, int clip, int32_t* best_id, double* phases6, int cap, int* P) {
+  if (!t || !best_id || !phases6 || !P || clip < 0 || clip >= t->n_clips) { set_error("bad argument"); return VBT_ERR_ARG; }
+  if (!t->finished) { set_error("vbt_tracker_phases before vbt_tracker_finish"); return VBT_ERR_STATE; }
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  int n = 0;
+  VBT_HIP_CHECK(hipMemcpy(&n, t->nph + clip, sizeof(int), hipMemcpyDeviceToHost));
+  VBT_HIP_CHECK(hipMemcpy(best_id, t->best + clip, sizeof(int), hipMemcpyDeviceToHost));
+  if (n > cap) { set_error("clip %d has %d phases, buffer holds %d", clip, n, cap); return VBT_ERR_CAPACITY; }
+  if (n) VBT_HIP_CHECK(hipMemcpy(phases6, t->phases + (size_t)clip * MAXPH * 6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+  *P = n;
+  return VBT_OK;
+}
+
+int vbt_analyze(const double* cols7, int T, int preprocess, int flush, double plate_diameter, double diff_threshold,
+                double min_distance, double* phases6, int cap, int* P, int device) {
+  if (!cols7 && T > 0) { set_error("vbt_analyze: NULL rows"); return VBT_ERR_ARG; }
+  if (!phases6 || !P || T < 0) { set_error("vbt_analyze: bad argument"); return VBT_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_error("vbt_analyze: HIP device %d not available (%d visible) - no CPU fallback", device, ndev);
+    return VBT_ERR_HIP;
+  }
+  VBT_HIP_CHECK(hipSetDevice(device));
+  *P = 0;
+  if (T == 0) return VBT_OK;
+  double *dc = nullptr, *ds = nullptr, *dp = nullptr;
+  int *dn = nullptr, *dT = nullptr;
+  VBT_HIP_CHECK(hipMalloc((void**)&dc, sizeof(double) * 7 * T));
+  VBT_HIP_CHECK(hipMalloc((void**)&ds, sizeof(double) * 5 * T));
+  VBT_HIP_CHECK(hipMalloc((void**)&dp, sizeof(double) * 6 * MAXPH));
+  VBT_HIP_CHECK(hipMalloc((void**)&dn, sizeof(int)));
+  VBT_HIP_CHECK(hipMalloc((void**)&dT, sizeof(int)));
+  VBT_HIP_CHECK(hipMemcpy(dc, cols7, sizeof(double) * 7 * T, hipMemcpyHostToDevice));
+  VBT_HIP_CHECK(hipMemcpy(dT, &T, sizeof(int), hipMemcpyHostToDevice));
+  VtParams vp{plate_diameter, diff_threshold, min_distance, preprocess, flush};
+  analyze_kernel<<<1, 64>>>(dc, dT, T, vp, ds, dp, dn);
+  int n = 0;
+  hipError_t e = hipMemcpy(&n, dn, sizeof(int), hipMemcpyDeviceToHost);
+  int rc = VBT_OK;
+  if (e != hipSuccess) { set_error("analyze kernel failed: %s", hipGetErrorString(e)); rc = VBT_ERR_HIP; }
+  else if (n > cap) { set_error("%d phases, buffer holds %d", n, cap); rc = VBT_ERR_CAPACITY; }
+  else {
+    if (n) (void)hipMemcpy(phases6, dp, sizeof(double) * 6 * n, hipMemcpyDeviceToHost);
+    *P = n;
+  }
+  (void)hipFree(dc); (void)hipFree(ds); (void)hipFree(dp); (void)hipFree(dn); (void)hipFree(dT);
+  return rc;
+}
+
+}  // extern "C"
