@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec end-to-end (detect + NMS + track), EfficientDet-Lite0 320x320.
+
+One STEP = one pass of the hot path over one batch: frame t of each of `--clips` (default 64)
+synthetic clips per GPU -> int8 EfficientDet-Lite0 -> decode + NMS -> one OC-SORT step per clip,
+all enqueued on one HIP stream with the frames already resident in HBM.  After the K timed steps
+the clips are closed inside the timed region too: export-id selection + preprocessing +
+VelocityTracker on the device, then (N > 1) one RCCL all-gather of the per-clip result records.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; ranks own disjoint clips, no
+   data-path collective -> "weak" scaling; the only exchange is the final result gather.)
+
+Prints ONE JSON line on rank 0 (see the keys at the bottom).  `roofline` is for the dominant kernel
+family, timed with HIP events on the launch stream in a separate pass of the same process;
+`cpu_baseline` times the CPU oracle (a port: the reference's TFLite path cannot run here) on a
+bounded sample of the same workload on rank 0 at N = 1.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MODEL = os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm")
+
+
+def make_frames(clip_seeds, t0, n_steps, size=320):
+    """[n_steps, n_clips, S, S, 3] uint8: frame t0+i of every clip."""
+    from vbt_amd import synth
+    bgs = [synth.background(s, size) for s in clip_seeds]
+    out = np.empty((n_steps, len(clip_seeds), size, size, 3), np.uint8)
+    for i in range(n_steps):
+        for c, bg in enumerate(bgs):
+            out[i, c] = synth.render(bg, t0 + i)
+    return out
+
+
+def cpu_baseline(n_frames, threads):
+    """Oracle (CPU port) on a bounded sample: detector for n_frames frames (OpenMP over frames),
+    then OC-SORT + rep analysis in numpy/python over the detections, as 8 clips."""
+    from oracle import detector_ref, ocsort_np, velocity
+    n_clips = 8
+    per = max(n_frames // n_clips, 1)
+    frames = make_frames(list(range(n_clips)), 0, per)               # [per, 8, ...]
+    flat = np.ascontiguousarray(frames.reshape(-1, *frames.shape[2:]))
+    t0 = time.perf_counter()
+    boxes, scores, classes, counts = detector_ref.run_batch(MODEL, flat, threads=threads)
+    t_det = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    boxes = boxes.reshape(per, n_clips, 25, 4)
+    scores = scores.reshape(per, n_clips, 25)
+    counts = counts.reshape(per, n_clips)
+    for c in range(n_clips):
+        dets, times = [], []
+        for f in range(per):
+            d = [[boxes[f, c, i, 1], boxes[f, c, i, 0], boxes[f, c, i, 3], boxes[f, c, i, 2], scores[f, c, i], 0.0]
+                 for i in range(counts[f, c]) if scores[f, c, i] >= 0.5]
+            dets.append(np.asarray(d, np.float64).reshape(-1, 6))
+            times.append((f + 1) / 60.0)
+        rows = ocsort_np.track_boxes(dets, times)
+        if rows["id"]:
+            ids = np.asarray(rows["id"])
+            m = ids == np.bincount(ids).argmax()
+            velocity.analyze_track(*[np.asarray(rows[k])[m].tolist() for k in
+                                     ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width")])
+    t_trk = time.perf_counter() - t1
+    n = per * n_clips
+    return {"value": n / (t_det + t_trk), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} synthetic 320x320 frames ({n_clips} clips x {per}), oracle/detector.c with {threads} OpenMP threads "
+                      f"({t_det:.2f} s) + oracle OC-SORT/VelocityTracker in numpy, 1 thread ({t_trk:.2f} s)",
+            "host_cpu": _cpu_name(), "host_cores_visible": os.cpu_count()}
+
+
+def _cpu_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--clips", type=int, default=64, help="clips per GPU = detector batch")
+    ap.add_argument("--unique-steps", type=int, default=64, help="distinct frame sets kept in HBM and cycled")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from vbt_amd import _lib
+    from vbt_amd.track import Pipeline
+    n, K, W = args.clips, args.steps, args.warmup
+    U = max(1, min(args.unique_steps, K + W))
+    seeds = [rank * n + c for c in range(n)]                        # ranks own disjoint clips
+    frames = torch.from_numpy(make_frames(seeds, 0, U)).to(dev)      # resident in HBM before timing
+    pipe = Pipeline(MODEL, n, max_frames=K + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    fbytes = frames[0].numel()
+
+    def run_steps(count, start):
+        for i in range(count):
+            pipe.step(frames.data_ptr() + ((start + i) % U) * fbytes, stream)
+
+    run_steps(W, 0)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(K, W)
+    pipe.finish(stream)
+    # result record per clip: [best_id, n_rows, n_phases, 32 x (t0,t1,y0,y1,rom,type)]
+    rec = np.zeros((n, 3 + 32 * 6), np.float64)
+    nrows = 0
+    for c in range(n):
+        best, ph = pipe.phases(c)
+        st = pipe.tracker.status(c)
+        nrows += st["rows"]
+        rec[c, 0], rec[c, 1], rec[c, 2] = best, st["rows"], len(ph)
+        rec[c, 3:3 + 6 * min(len(ph), 32)] = ph[:32].reshape(-1)
+    if dist is not None:                                             # the one exchange of the path: RCCL all-gather
+        mine = torch.from_numpy(rec).to(dev)
+        allrec = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        dist.all_gather_into_tensor(allrec, mine)
+        rec_all = allrec.cpu().numpy()
+    else:
+        rec_all = rec[None]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    overflow = sum(pipe.tracker.status(c)["overflow"] for c in range(n))
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        L = _lib.lib()
+        stats = (_lib.KernelStat * 8)()
+        cnt = ctypes.c_int()
+        _lib.check(L.vbt_model_kernel_stats(pipe.interpreter.handle, n, stats, 8, ctypes.byref(cnt)))
+        ms = (ctypes.c_double * 8)()
+        _lib.check(L.vbt_model_profile(pipe.interpreter.handle, frames.data_ptr(), n, 10, stream, ms, 8))
+        fam = max(range(cnt.value), key=lambda i: ms[i])
+        s = stats[fam]
+        per_launch_s = ms[fam] * 1e-3 / s.launches
+        achieved = (s.algorithmic_bytes / s.launches) / per_launch_s
+        roofline = {"bound": "hbm", "kernel": s.name.decode(), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK, "traffic": None, "launches_per_step": s.launches,
+                    "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": s.algorithmic_bytes / s.launches,
+                    "families_ms_per_step": {stats[i].name.decode(): round(ms[i], 4) for i in range(cnt.value)},
+                    "whole_net_algorithmic_GBps": sum(stats[i].algorithmic_bytes for i in range(cnt.value)) /
+                    (sum(ms[i] for i in range(cnt.value)) * 1e-3) / 1e9}
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        cpu = cpu_baseline(args.cpu_frames, threads=max(1, min(16, os.cpu_count() or 1)))
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        total_frames = K * n * world
+        out = {
+            "metric": "frames/sec end-to-end (detect+NMS+track), EfficientDet-Lite0 320x320",
+            "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8", "data": "synthetic",
+            "config": {"workload": "EfficientDet-Lite0 320x320 full-integer (int8 act/weights, int32 acc), synthetic clips "
+                                   "batched frame-wise, decode+NMS+OC-SORT on device every step, export-id selection + "
+                                   "VelocityTracker on device at clip end (inside the timed region)",
+                       "clips_per_gpu": n, "batch": n, "frames_per_clip": K, "model_file": os.path.basename(MODEL),
+                       "weights": "seeded synthetic (PCG64), post-training int8 quantised", "parallelism": f"clip-sharded x{world}"},
+            "rows_emitted_rank0": int(nrows), "tracker_overflow_rank0": int(overflow),
+            "clips_with_result": int((rec_all[..., 1] > 0).sum()),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

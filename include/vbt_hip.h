@@ -70,6 +70,12 @@ int vbt_model_read_tensor(vbt_model* m, int tensor_id, int B, int8_t* host_out);
 int vbt_detect_async(vbt_model* m, const uint8_t* frames_dev, int B, void* stream,
                      float* boxes_dev, float* scores_dev, float* classes_dev, int32_t* counts_dev);
 
+/* preprocess_image (reference odt.py:10-19): bilinear resize (half-pixel centres, float32) of
+ * uint8 [B,H,W,3] frames to [B,h,w,3] + truncating uint8 cast; swap_rb != 0 also swaps channels 0
+ * and 2 (cv2 BGR -> RGB, reference track.py:171).  src/dst are host or device pointers. */
+int vbt_resize_frames(const uint8_t* src, int B, int H, int W, int src_on_device, uint8_t* dst, int h, int w,
+                      int dst_on_device, int swap_rb, int device, void* stream);
+
 /* Per-kernel-family accounting of the last enqueued forward: fills up to `cap` entries.
  * Algorithmic bytes = inputs read once + output written once + weights once. */
 typedef struct {

@@ -1,0 +1,115 @@
+"""GPU end-to-end: frames -> detect -> NMS -> OC-SORT -> export id -> rep analysis through the fused
+Pipeline, against the oracle chain on the same seeded frames; plus the odt/track call shapes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+COLS = ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width")
+
+
+def _oracle_chain(oracle_lib, model_path, frames, fps=60.0, thr=0.5):
+    from oracle import ocsort_np
+    T, n = frames.shape[:2]
+    ob, os_, oc, on = oracle_lib.run_batch(model_path, frames.reshape(-1, *frames.shape[2:]), threads=8)
+    ob, os_, on = ob.reshape(T, n, 25, 4), os_.reshape(T, n, 25), on.reshape(T, n)
+    rows = []
+    for c in range(n):
+        dets = [np.asarray([[ob[t, c, i, 1], ob[t, c, i, 0], ob[t, c, i, 3], ob[t, c, i, 2], os_[t, c, i], 0.0]
+                            for i in range(on[t, c]) if os_[t, c, i] >= thr], np.float64).reshape(-1, 6) for t in range(T)]
+        rows.append(ocsort_np.track_boxes(dets, [(t + 1) / fps for t in range(T)]))
+    return (ob, os_, on), rows
+
+
+def test_pipeline_equals_oracle_chain(oracle_lib, model_path):
+    import torch
+    from oracle import velocity as ov
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    n, T = 6, 24
+    frames = np.stack([np.stack([synth.render(synth.background(40 + c), 9 * c + t) for c in range(n)]) for t in range(T)])
+    fd = torch.from_numpy(frames).to("cuda:0")
+    pipe = Pipeline(model_path, n, max_frames=T, fps=60.0)
+    st = torch.cuda.current_stream().cuda_stream
+    dets = []
+    for t in range(T):
+        pipe.step(fd[t].data_ptr(), st)
+        dets.append(pipe.detections())
+    pipe.finish(st)
+    (ob, os_, on), rows = _oracle_chain(oracle_lib, model_path, frames)
+    for t in range(T):
+        b, s, c, k = dets[t]
+        assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t])
+    total = 0
+    for c in range(n):
+        got, want = pipe.rows(c), rows[c]
+        assert got["id"] == want["id"]
+        for k in COLS:
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), (c, k)
+        total += len(got["id"])
+        # export id + phases
+        ids = np.asarray(want["id"])
+        cum = {}
+        for tid in np.unique(ids):
+            m = ids == tid
+            d = np.sqrt(np.diff(np.asarray(want["x"])[m]) ** 2 + np.diff(np.asarray(want["y"])[m]) ** 2)
+            if len(d):
+                cum[int(tid)] = d.sum()
+        best, ph = pipe.phases(c)
+        if cum:
+            want_id = max(cum, key=cum.get)
+            assert best == want_id
+            m = ids == want_id
+            wp = ov.analyze_track(*[np.asarray(want[k])[m].tolist() for k in COLS])
+            assert [list(r) for r in ph] == [p.as_row() for p in wp]
+        else:
+            assert best == -1 and len(ph) == 0
+    assert total > 20
+
+
+def test_track_function_and_run_odt_call_shapes(oracle_lib, model_path):
+    """track(src, interpreter, ...) with Interpreter / run_odt / OCSort drop-ins (reference track.py:129-260)."""
+    from vbt_amd import synth
+    from vbt_amd.interpreter import Interpreter
+    from vbt_amd.odt import results_to_sorttracker_inputs, run_odt
+    from vbt_amd.track import track
+    frames = synth.clip_frames(3, 0, 10)
+    it = Interpreter(model_path=model_path, num_threads=4)
+    it.allocate_tensors()
+    assert tuple(it.get_input_details()[0]["shape"]) == (1, 320, 320, 3)
+    res = run_odt(frames[0], it, threshold=0.0)
+    det = oracle_lib.OracleDetector(model_path)
+    ob, os_, oc, on = det.run(frames[0])
+    assert len(res) == on == 25
+    assert all(np.array_equal(r["bounding_box"], ob[i]) and r["score"] == os_[i] for i, r in enumerate(res))
+    assert results_to_sorttracker_inputs(res).shape == (25, 6) and results_to_sorttracker_inputs([]).shape == (0, 6)
+    data = track(frames, it, detection_treshold=0.5, fps=60.0)
+    _, rows = _oracle_chain(oracle_lib, model_path, frames[:, None])
+    assert data["id"] == rows[0]["id"]
+    for k in COLS:
+        assert np.array_equal(np.asarray(data[k]), np.asarray(rows[0][k])), k
+    data16 = track(frames, it, frame_stride=16)      # the snapshot's `frame_count % 16` (track.py:166)
+    assert data16["id"] == []
+
+
+def test_preprocess_resize_matches_oracle():
+    """reference odt.py:10-19 at real source sizes (portrait 1080x1920 like the reference clips), up and down."""
+    from oracle.preprocess import preprocess_image as ref
+    from vbt_amd.odt import preprocess_image
+    rng = np.random.default_rng(5)
+    for (H, W), (h, w) in (((1920, 1080), (320, 320)), ((416, 416), (320, 320)), ((200, 333), (448, 448)), ((320, 320), (320, 320)), ((7, 5), (320, 320))):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        got, orig = preprocess_image(img, (h, w))
+        assert got.shape == (1, h, w, 3) and got.dtype == np.uint8 and orig is not None
+        assert np.array_equal(got, ref(img, (h, w))), ((H, W), (h, w))
+
+
+def test_errors_are_loud(model_path):
+    from vbt_amd import _lib
+    from vbt_amd.interpreter import Interpreter
+    with pytest.raises(_lib.VbtError):
+        Interpreter("/nonexistent/model.vbtm")
+    it = Interpreter(model_path, max_batch=2)
+    with pytest.raises(_lib.VbtError):
+        it.detect(np.zeros((3, 320, 320, 3), np.uint8))          # batch > max_batch
+    with pytest.raises(ValueError):
+        it.get_signature_runner()(images=np.zeros((1, 100, 100, 3), np.uint8))

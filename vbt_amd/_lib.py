@@ -35,6 +35,7 @@ _SIGS = {
     "vbt_detect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "vbt_detect_async": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vbt_model_read_tensor": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "vbt_resize_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vbt_model_kernel_stats": (c_int, [c_void_p, c_int, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),
     "vbt_model_profile": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_double), c_int]),
     "vbt_tracker_create": (c_int, [c_int, c_int, ctypes.POINTER(TrackerParams), c_int, ctypes.POINTER(c_void_p)]),
@@ -58,6 +59,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise VbtError(f"{LIB_PATH} is missing: build it with `python -m vbt_amd.build` "
                            "(__graft_entry__.build()). vbt_amd has no CPU fallback.")
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64/libhsa-runtime64. If this
+        # library were loaded first it would bind to /opt/rocm's copy and torch's later initialisation would
+        # find "no HIP GPUs".  Importing torch first puts its runtime in the global symbol scope, and the
+        # hip* symbols of libvbt_hip.so resolve to that same runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)          # AttributeError if the library does not export the symbol

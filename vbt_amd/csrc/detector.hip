@@ -532,6 +532,39 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// preprocess_image (reference odt.py:10-19): tf.image.resize bilinear with half-pixel centres
+// [EXTERNAL TF2 ResizeBilinear: in = (out+0.5)*scale-0.5, lower = max(floor(in),0),
+// upper = min(ceil(in), size-1), lerp = in - floor(in); top + (bottom-top)*ly], float32,
+// then tf.cast(..., uint8) = truncation.  Optional BGR->RGB swap (reference track.py:171).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                              long total, int H, int W, int h, int w, float sy, float sx,
+                                                              int swap_rb) {
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int ox = (int)(idx % w);
+  long t = idx / w;
+  int oy = (int)(t % h);
+  long b = t / h;
+  float iy = ((float)oy + 0.5f) * sy - 0.5f, ix = ((float)ox + 0.5f) * sx - 0.5f;
+  float fy = floorf(iy), fx = floorf(ix);
+  int y0 = max((int)fy, 0), y1 = min((int)ceilf(iy), H - 1);
+  int x0 = max((int)fx, 0), x1 = min((int)ceilf(ix), W - 1);
+  float ly = iy - fy, lx = ix - fx;
+  const uint8_t* s = src + b * (long)H * W * 3;
+  uint8_t* d = dst + ((b * h + oy) * (long)w + ox) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float tl = (float)s[((long)y0 * W + x0) * 3 + c], tr = (float)s[((long)y0 * W + x1) * 3 + c];
+    float bl = (float)s[((long)y1 * W + x0) * 3 + c], br = (float)s[((long)y1 * W + x1) * 3 + c];
+    float top = tl + (tr - tl) * lx;
+    float bot = bl + (br - bl) * lx;
+    float v = top + (bot - top) * ly;
+    d[swap_rb ? 2 - c : c] = (uint8_t)(int)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
 enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_COUNT };
@@ -989,6 +1022,41 @@ int vbt_model_read_tensor(vbt_model* m, int id, int B, int8_t* host_out) {
   if (B < 1 || B > m->max_batch) { set_error("bad batch"); return VBT_ERR_CAPACITY; }
   VBT_HIP_CHECK(hipDeviceSynchronize());
   VBT_HIP_CHECK(hipMemcpy(host_out, m->tptr[id], m->telems[id] * B, hipMemcpyDeviceToHost));
+  return VBT_OK;
+}
+
+int vbt_resize_frames(const uint8_t* src, int B, int H, int W, int src_on_device, uint8_t* dst, int h, int w, int dst_on_device,
+                      int swap_rb, int device, void* stream) {
+  if (!src || !dst || B < 1 || H < 1 || W < 1 || h < 1 || w < 1) { set_error("vbt_resize_frames: bad argument"); return VBT_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_error("vbt_resize_frames: HIP device %d not available (%d visible) - no CPU fallback", device, ndev);
+    return VBT_ERR_HIP;
+  }
+  VBT_HIP_CHECK(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  size_t sb = (size_t)B * H * W * 3, db = (size_t)B * h * w * 3;
+  uint8_t *ds = nullptr, *dd = nullptr;
+  const uint8_t* sp = src;
+  uint8_t* dp = dst;
+  if (!src_on_device) {
+    VBT_HIP_CHECK(hipMalloc((void**)&ds, sb));
+    VBT_HIP_CHECK(hipMemcpyAsync(ds, src, sb, hipMemcpyHostToDevice, st));
+    sp = ds;
+  }
+  if (!dst_on_device) {
+    VBT_HIP_CHECK(hipMalloc((void**)&dd, db));
+    dp = dd;
+  }
+  long total = (long)B * h * w;
+  float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  resize_bilinear_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(sp, dp, total, H, W, h, w, sy, sx, swap_rb);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !dst_on_device) e = hipMemcpyAsync(dst, dd, db, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && (ds || dd)) e = hipStreamSynchronize(st);
+  if (ds) (void)hipFree(ds);
+  if (dd) (void)hipFree(dd);
+  if (e != hipSuccess) { set_error("vbt_resize_frames failed: %s", hipGetErrorString(e)); return VBT_ERR_HIP; }
   return VBT_OK;
 }
 

@@ -225,75 +225,100 @@ __device__ inline double diou_xyxy(const double* a, const double* b) {
 }
 
 // ------------------------------------------------------------------------------------------
-// wave-parallel rectangular linear assignment (n rows <= m cols <= 64, lanes = columns).
-// cost(i, j) = tr ? C[j*ld + i] : C[i*ld + j].  Writes row2col[0..n).
+// wave-parallel rectangular linear assignment (nr rows <= nc cols <= 64, lanes = columns).
+// cost(i, j) = tr ? C[j*ld + i] : C[i*ld + j].  Writes row2col[0..nr).
+// OC-SORT's second association compares detections with never-observed trackers whose placeholder
+// boxes are identical, so exact cost ties are routine and the result depends on the solver's tie
+// rule.  This is therefore a faithful lane-parallel port of the solver the oracle uses
+// [EXTERNAL: scipy.optimize.linear_sum_assignment = Crouse's shortest augmenting path,
+// rectangular_lsap.cpp]: same `remaining` order (reverse fill, swap-with-last removal), same
+// selection rule (lowest cost; among equals the LAST unassigned column scanned, else the first),
+// same dual updates and the same floating-point expression ((minVal + c) - u) - v.
 // ------------------------------------------------------------------------------------------
 struct LapShared {
-  double u[MAXT + 1];
-  int p[MAXT + 1];
-  int way[MAXT + 1];
+  double u[MAXT];
+  double spc[MAXT];
+  int col4row[MAXT];
+  int row4col[MAXT];
+  int path[MAXT];
+  int remaining[MAXT];
 };
 
-__device__ inline void wave_argmin(double v, int lane, double& vmin, int& imin) {
-  double bv = v;
-  int bi = lane;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    double ov = __shfl_xor(bv, o);
-    int oi = __shfl_xor(bi, o);
-    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
-  vmin = bv;
-  imin = bi;
-}
-
-__device__ void lap_solve(const double* C, int ld, bool tr, int n, int m, int* row2col, LapShared& S, int lane) {
-  const double INF = 1e300;
+__device__ void lap_solve(const double* C, int ld, bool tr, int nr, int nc, int* row2col, LapShared& S, int lane) {
+  const double INF = __builtin_inf();
   double v = 0.0;
-  if (lane <= n) S.u[lane] = 0.0;
-  S.p[lane + 1] = 0;
-  if (lane == 0) S.p[0] = 0;
+  if (lane < nr) { S.u[lane] = 0.0; S.col4row[lane] = -1; }
+  if (lane < nc) { S.row4col[lane] = -1; S.path[lane] = -1; }
   __syncthreads();
-  for (int i = 1; i <= n; i++) {
-    if (lane == 0) S.p[0] = i;
+  for (int cur = 0; cur < nr; cur++) {
+    // ---- augmenting_path ----
+    double minVal = 0.0;
+    int num_rem = nc;
+    int pos = lane < nc ? nc - 1 - lane : -1;   // remaining[it] = nc - it - 1
+    if (lane < nc) S.remaining[nc - 1 - lane] = lane;
+    double spc = INF;
+    unsigned long long sr = 0ull;
+    int i = cur, sink = -1;
     __syncthreads();
-    int j0 = 0;
-    double minv = INF;
-    bool used = false;
-    while (true) {
-      if (j0 > 0 && lane == j0 - 1) used = true;
-      int i0 = S.p[j0];
-      double ui0 = S.u[i0];
-      double cur = INF;
-      if (lane < m && !used) {
-        double c = (tr ? C[lane * ld + (i0 - 1)] : C[(i0 - 1) * ld + lane]) - ui0 - v;
-        if (c < minv) { minv = c; S.way[lane + 1] = j0; }
-        cur = minv;
+    while (sink == -1) {
+      sr |= 1ull << i;
+      const double ui = S.u[i];
+      const bool active = lane < nc && pos >= 0;
+      const int r4c = lane < nc ? S.row4col[lane] : 0;
+      if (active) {
+        double c = tr ? C[lane * ld + i] : C[i * ld + lane];
+        double r = ((minVal + c) - ui) - v;
+        if (r < spc) { S.path[lane] = i; spc = r; }
       }
-      double delta;
-      int jl;
-      wave_argmin(cur, lane, delta, jl);
+      double lowest = active ? spc : INF;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) lowest = fmin(lowest, __shfl_xor(lowest, o));
+      const bool cand = active && spc == lowest;
+      const unsigned long long un = __ballot(cand && r4c == -1);
+      int key;  // choose: unassigned candidates -> max position, else min position
+      if (un) key = (cand && r4c == -1) ? pos : -1;
+      else key = cand ? -pos : -(1 << 20);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
+      const int index = un ? key : -key;
+      minVal = lowest;
+      const int j = S.remaining[index];
+      const int jrow = S.row4col[j];
       __syncthreads();
-      if (lane < m) {
-        if (used) { S.u[S.p[lane + 1]] += delta; v -= delta; }
-        else minv -= delta;
-      }
-      if (lane == 0) S.u[S.p[0]] += delta;
+      if (jrow == -1) sink = j; else i = jrow;
+      // SC[j] = true ; remaining[index] = remaining[--num_remaining]
+      num_rem -= 1;
+      const int jl = S.remaining[num_rem];
       __syncthreads();
-      j0 = jl + 1;
-      if (S.p[j0] == 0) break;
+      if (lane == j) pos = -1;
+      if (lane == jl && jl != j) pos = index;
+      if (lane == 0) S.remaining[index] = jl;
+      __syncthreads();
     }
+    // ---- dual updates ----
+    if (lane < nc) S.spc[lane] = spc;
+    __syncthreads();
+    if (lane < nr) {
+      if (lane == cur) S.u[lane] += minVal;
+      else if ((sr >> lane) & 1ull) S.u[lane] += minVal - S.spc[S.col4row[lane]];
+    }
+    if (lane < nc && pos < 0) v -= minVal - spc;
+    __syncthreads();
+    // ---- augment ----
     if (lane == 0) {
-      int jj = j0;
-      do {
-        int j1 = S.way[jj];
-        S.p[jj] = S.p[j1];
-        jj = j1;
-      } while (jj);
+      int j = sink;
+      while (true) {
+        int ii = S.path[j];
+        S.row4col[j] = ii;
+        int t = S.col4row[ii];
+        S.col4row[ii] = j;
+        j = t;
+        if (ii == cur) break;
+      }
     }
     __syncthreads();
   }
-  if (lane < m && S.p[lane + 1] != 0) row2col[S.p[lane + 1] - 1] = lane;
+  if (lane < nr) row2col[lane] = S.col4row[lane];
   __syncthreads();
 }
 
@@ -305,7 +330,9 @@ struct StepShared {
   double tbox[MAXT][4];
   double iou[MAXD][MAXT];
   double cost[MAXD][MAXT];
-  int d2t[MAXD];      // detection -> tracker position (or -1)
+  int d2t[MAXD];      // detection -> tracker position paired by the first association (or -1)
+  int rej[MAXD];      // that pair was rejected (IoU below threshold)
+  int taken[MAXD];    // detection consumed by a tracker (first or second association)
   int r2c[MAXT];      // assignment scratch
   int um_d[MAXD];     // unmatched detections, in the reference's list order
   int um_t[MAXT];
@@ -384,7 +411,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
       colsum += io > p.iou_thr ? 1 : 0;
     }
   }
-  if (lane < MAXD) sh.d2t[lane] = -1;
+  if (lane < MAXD) { sh.d2t[lane] = -1; sh.rej[lane] = 0; sh.taken[lane] = 0; }
   __syncthreads();
   int maxcol = colsum;
 #pragma unroll
@@ -412,25 +439,27 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
       }
     }
   }
-  bool rejected = false;  // assigned but IoU below the threshold
+  // d2t[d]: tracker position the solver paired with detection d (-1 none); rej[d]: pair rejected (IoU < thr)
   if (lane < T && my_det >= 0) {
-    if (sh.iou[my_det][lane] < p.iou_thr) { rejected = true; sh.d2t[my_det] = -2; my_det = -1; }
-    else sh.d2t[my_det] = lane;
+    sh.d2t[my_det] = lane;
+    if (sh.iou[my_det][lane] < p.iou_thr) { sh.rej[my_det] = 1; my_det = -1; }
   }
   __syncthreads();
   if (lane < T && my_det >= 0) trk_update(st.trk[slot], sh.det[my_det], q44, q66, p.delta_t);
-  // unmatched lists in the reference's order: never-assigned ascending, then rejected ascending
+  // unmatched lists in the reference's order (it matters: the second association sees exact ties):
+  //   detections: never paired ascending, then rejected pairs in matched (= detection) order
+  //   trackers  : never paired ascending, then the trackers of the rejected pairs in the same order
   if (lane == 0) {
-    int n = 0;
-    for (int d = 0; d < nd; d++) if (sh.d2t[d] == -1) sh.um_d[n++] = d;
-    for (int d = 0; d < nd; d++) if (sh.d2t[d] == -2) sh.um_d[n++] = d;
+    unsigned long long paired = 0ull;
+    int n = 0, m = 0;
+    for (int d = 0; d < nd; d++) {
+      if (sh.d2t[d] < 0) sh.um_d[n++] = d;
+      else paired |= 1ull << sh.d2t[d];
+    }
+    for (int t = 0; t < T; t++) if (!((paired >> t) & 1ull)) sh.um_t[m++] = t;
+    for (int d = 0; d < nd; d++) if (sh.d2t[d] >= 0 && sh.rej[d]) { sh.um_d[n++] = d; sh.um_t[m++] = sh.d2t[d]; }
     sh.n_um_d = n;
-  }
-  {
-    bool unm = lane < T && my_det < 0;
-    unsigned long long m = __ballot(unm);
-    if (unm) sh.um_t[__popcll(m & ((1ull << lane) - 1ull))] = lane;
-    if (lane == 0) sh.n_um_t = __popcll(m);
+    sh.n_um_t = m;
   }
   __syncthreads();
   // ---- observation-centric recovery (second association on the last observations) ----
@@ -467,14 +496,14 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
       if (lane < nut && mine >= 0 && !(sh.iou[mine][lane] < p.iou_thr)) {
         int tp = sh.um_t[lane];
         trk_update(st.trk[st.order[tp]], sh.det[sh.um_d[mine]], q44, q66, p.delta_t);
-        sh.d2t[sh.um_d[mine]] = tp;
+        sh.taken[sh.um_d[mine]] = 1;
         sh.um_t[lane] = -1;
       }
       recovered = true;
       __syncthreads();
       if (lane == 0) {  // np.setdiff1d: sorted ascending
         int n = 0;
-        for (int d = 0; d < nd; d++) if (sh.d2t[d] < 0) sh.um_d[n++] = d;
+        for (int d = 0; d < nd; d++) if ((sh.d2t[d] < 0 || sh.rej[d]) && !sh.taken[d]) sh.um_d[n++] = d;
         sh.n_um_d = n;
       }
       __syncthreads();

@@ -1,0 +1,135 @@
+"""`track()` + export: the reference's per-clip hot loop (reference track.py:129-260, 103-126),
+and `Pipeline`, its batched MI355X form (n clips frame-wise through detect -> NMS -> tracker on
+one stream, rep analysis at the end).
+
+No GUI: drawing / imshow / VideoWriter (reference track.py:28-62,201-207,237-247) are out of
+scope.  Frame sources are arrays / iterables of RGB uint8 frames instead of
+cv2.VideoCapture (cv2 is not a dependency here).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from .interpreter import Interpreter
+from .ocsort import MultiClipTracker, OCSort
+from .odt import (calc_bounding_box_center, calc_plate_height, calc_plate_width, results_to_sorttracker_inputs,
+                  run_odt)
+
+MAX_AGE = 30                                   # reference track.py:22
+COLUMNS = ("id", "time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width")
+
+
+def track(src, interpreter, detection_treshold=0.5, display_image_height=720, video_path=None, fps=30.0, frame_stride=1):
+    """Per-frame loop of reference track.py:159-234 with the reference's object call shapes.
+    src: iterable of RGB uint8 frames.  frame_stride=16 reproduces `frame_count % 16` of the
+    snapshot (track.py:166); the committed DataFrames were made with stride 1."""
+    data = {k: [] for k in COLUMNS}
+    tracker = OCSort(max_age=MAX_AGE, asso_func="diou", iou_threshold=0.1)
+    frame_count = 0
+    for frame in src:
+        frame_count += 1
+        if frame_stride > 1 and frame_count % frame_stride:
+            continue
+        time = frame_count / fps
+        results = run_odt(frame=frame, interpreter=interpreter, threshold=detection_treshold)
+        if results == []:
+            continue
+        tracker_out = tracker.update(results_to_sorttracker_inputs(results), [], time=time)
+        trackers = tracker.trackers
+        for res in tracker_out:
+            xmin, ymin, xmax, ymax, tracking_id, _, score = res
+            bounding_box = [ymin, xmin, ymax, xmax]
+            tracking_id = int(tracking_id)
+            kf = None
+            for trk in trackers:
+                if trk.id == tracking_id - 1:
+                    kf = trk.kf
+                    break
+            dx, dy = kf.x.flatten()[4:6]
+            x_center, y_center = calc_bounding_box_center(bounding_box)
+            data["id"].append(tracking_id)
+            data["time"].append(time)
+            data["x"].append(x_center)
+            data["y"].append(y_center)
+            data["dx"].append(dx)
+            data["dy"].append(dy)
+            data["norm_plate_height"].append(calc_plate_height(bounding_box))
+            data["norm_plate_width"].append(calc_plate_width(bounding_box))
+    return data
+
+
+def export_dataframe(data, src_name, model_path, df_dir=None, write=True):
+    """reference track.py:103-126: sort by (id,time) keeping the original row labels, pick the id with
+    the largest cumulative path length, name the file f'{video}_id{id}_{model}.pkl.gz'."""
+    import pandas as pd
+    df = pd.DataFrame.from_dict(data)
+    df = df.sort_values(by=["id", "time"])
+    df2 = df.copy()
+    df2["distance"] = np.where(df2["id"] == df2["id"].shift(),
+                               ((df2["x"] - df2["x"].shift()) ** 2 + (df2["y"] - df2["y"].shift()) ** 2) ** 0.5, np.nan)
+    df2["cumulative_distance"] = df2.groupby("id")["distance"].cumsum()
+    max_distance_id = df2.loc[df2["cumulative_distance"].idxmax(), "id"]
+    model_name = os.path.basename(model_path).split(".")[0]
+    df_filename = f'{os.path.basename(src_name).split(".")[0]}_id{max_distance_id}_{model_name}.pkl.gz'
+    df_path = df_filename if df_dir is None else os.path.join(df_dir, df_filename)
+    if write:
+        if df_dir is not None:
+            os.makedirs(df_dir, exist_ok=True)
+        df.to_pickle(df_path)
+    return df, int(max_distance_id), df_path
+
+
+class Pipeline:
+    """n clips processed frame-wise: step(frames[n,H,W,3] on the device) enqueues detect+NMS and one
+    tracker step for every clip on `stream`; finish() selects each clip's export id and runs the rep
+    analysis on the device.  Nothing leaves the GPU until rows()/phases() are read."""
+
+    def __init__(self, model_path, n_clips, max_frames, fps=60.0, detection_treshold=0.5, device=0, rows_per_frame=4,
+                 plate_diameter=0.45):
+        self.n = int(n_clips)
+        self.fps = np.broadcast_to(np.asarray(fps, np.float64), (self.n,)).copy()
+        self.thr = float(detection_treshold)
+        self.plate_diameter = plate_diameter
+        self.interpreter = Interpreter(model_path, device=device, max_batch=self.n)
+        self.tracker = MultiClipTracker(self.n, int(max_frames) * rows_per_frame, max_age=MAX_AGE, asso_func="diou",
+                                        iou_threshold=0.1, device=device)
+        self.frame_count = 0
+        self._dev = device
+        self._bufs = None
+        self._times = np.zeros(self.n, np.float64)
+
+    def _alloc(self):
+        import torch
+        dev = torch.device(f"cuda:{self._dev}")
+        n = self.n
+        self._bufs = (torch.empty((n, 25, 4), dtype=torch.float32, device=dev), torch.empty((n, 25), dtype=torch.float32, device=dev),
+                      torch.empty((n, 25), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.int32, device=dev))
+
+    def step(self, frames_dev_ptr, stream=None):
+        """frames_dev_ptr: device pointer of uint8 [n,H,W,3] (frame `frame_count+1` of every clip)."""
+        if self._bufs is None:
+            self._alloc()
+        b, s, c, k = self._bufs
+        self.frame_count += 1
+        np.divide(float(self.frame_count), self.fps, out=self._times)          # time = frame_count / fps (track.py:169)
+        L = _lib.lib()
+        _lib.check(L.vbt_detect_async(self.interpreter.handle, frames_dev_ptr, self.n, stream, b.data_ptr(), s.data_ptr(),
+                                      c.data_ptr(), k.data_ptr()))
+        _lib.check(L.vbt_tracker_update_from_detections(self.tracker.handle, b.data_ptr(), s.data_ptr(), k.data_ptr(),
+                                                        self._times.ctypes.data, self.thr, stream))
+
+    def finish(self, stream=None):
+        self.tracker.finish(self.plate_diameter, stream=stream)
+
+    def rows(self, clip):
+        return self.tracker.rows(clip)
+
+    def phases(self, clip):
+        return self.tracker.phases(clip)
+
+    def detections(self):
+        """Last step's detector outputs (host copies) - for tests."""
+        b, s, c, k = self._bufs
+        return b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), k.cpu().numpy()
