@@ -170,11 +170,11 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         L = _lib.lib()
-        stats = (_lib.KernelStat * 8)()
+        stats = (_lib.KernelStat * 16)()
         cnt = ctypes.c_int()
-        _lib.check(L.vbt_model_kernel_stats(pipe.interpreter.handle, n, stats, 8, ctypes.byref(cnt)))
-        ms = (ctypes.c_double * 8)()
-        _lib.check(L.vbt_model_profile(pipe.interpreter.handle, frames.data_ptr(), n, 10, stream, ms, 8))
+        _lib.check(L.vbt_model_kernel_stats(pipe.interpreter.handle, n, stats, 16, ctypes.byref(cnt)))
+        ms = (ctypes.c_double * 16)()
+        _lib.check(L.vbt_model_profile(pipe.interpreter.handle, frames.data_ptr(), n, 10, stream, ms, 16))
         fam = max(range(cnt.value), key=lambda i: ms[i])
         s = stats[fam]
         per_launch_s = ms[fam] * 1e-3 / s.launches

@@ -44,7 +44,21 @@ typedef struct vbt_model vbt_model;
 
 /* container_path: a VBTM model container (vbt_amd/container.py); max_batch frames per vbt_detect. */
 int vbt_model_create(const char* container_path, int device, int max_batch, vbt_model** out);
+/* flags: VBT_MODEL_NO_FUSION runs every graph op as its own kernel (every tensor readable by
+ * vbt_model_read_tensor); the default fuses MBConv / SeparableConv blocks on LDS tiles.
+ * vbt_model_create == _ex with VBT_MODEL_DEFAULT_FLAGS (or the integer in the environment variable
+ * VBT_FUSION_FLAGS). */
+#define VBT_MODEL_NO_FUSION 1
+#define VBT_MODEL_NO_MBCONV_FUSION 2
+#define VBT_MODEL_NO_SEPCONV_FUSION 4
+#define VBT_MODEL_NO_AUTOTUNE 8     /* keep the heuristic plan (most fused alternative, default kernel variants) */
+#define VBT_MODEL_DEFAULT_FLAGS 0
+int vbt_model_create_ex(const char* container_path, int device, int max_batch, int flags, vbt_model** out);
 void vbt_model_destroy(vbt_model* m);
+/* 1 if graph tensor `tensor_id` is written to HBM by the execution plan, 0 if it only exists in LDS */
+int vbt_model_tensor_materialized(const vbt_model* m, int tensor_id);
+/* kernels launched per forward */
+int vbt_model_num_launches(const vbt_model* m);
 /* shape = {max_batch, H, W, 3} */
 int vbt_model_input_shape(const vbt_model* m, int shape[4]);
 int vbt_model_num_tensors(const vbt_model* m);

@@ -10,6 +10,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 model = os.path.join(os.path.dirname(__file__), "..", "models", "efficientdet_lite0_synth.vbtm")
 it = Interpreter(model, max_batch=B)
+print('launches per forward:', it.num_launches())
 frames = np.stack([synth.render(synth.background(s), 3 * s) for s in range(min(B, 16))])
 frames = np.concatenate([frames] * ((B + len(frames) - 1) // len(frames)))[:B]
 dev = torch.device("cuda:0")
@@ -29,10 +30,10 @@ for _ in range(steps): step()
 torch.cuda.synchronize()
 dt = (time.time() - t) / steps
 print(f"B={B}: {dt*1e3:.3f} ms/step, {B/dt:.0f} frames/s")
-stats = (_lib.KernelStat * 8)(); n = ctypes.c_int()
-_lib.check(L.vbt_model_kernel_stats(it.handle, B, stats, 8, ctypes.byref(n)))
-ms = (ctypes.c_double * 8)()
-_lib.check(L.vbt_model_profile(it.handle, fd.data_ptr(), B, 5, st, ms, 8))
+stats = (_lib.KernelStat * 16)(); n = ctypes.c_int()
+_lib.check(L.vbt_model_kernel_stats(it.handle, B, stats, 16, ctypes.byref(n)))
+ms = (ctypes.c_double * 16)()
+_lib.check(L.vbt_model_profile(it.handle, fd.data_ptr(), B, 5, st, ms, 16))
 tot = sum(ms[i] for i in range(n.value))
 for i in range(n.value):
     s = stats[i]

@@ -27,7 +27,10 @@ _SIGS = {
     "vbt_last_error": (c_char_p, []),
     "vbt_device_count": (c_int, []),
     "vbt_model_create": (c_int, [c_char_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "vbt_model_create_ex": (c_int, [c_char_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "vbt_model_destroy": (None, [c_void_p]),
+    "vbt_model_tensor_materialized": (c_int, [c_void_p, c_int]),
+    "vbt_model_num_launches": (c_int, [c_void_p]),
     "vbt_model_input_shape": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "vbt_model_num_tensors": (c_int, [c_void_p]),
     "vbt_model_num_ops": (c_int, [c_void_p]),

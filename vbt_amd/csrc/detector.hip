@@ -22,6 +22,8 @@
 
 namespace vbt {
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -29,8 +31,6 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-
-typedef int v4i __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -45,10 +45,35 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
   return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)(d & 255) << 24);
 }
 
+// The same requantisation in 5 VALU ops + 1 pack op per element: clamp(rne(t) + zp, lo, hi) ==
+// clamp(rne(t), lo - zp, hi - zp) + zp because every quantity after rne() is an exact small integer in
+// fp32; the result is produced in the unsigned domain (q + 128 in [0,255]) so v_cvt_pk_u8_f32 can pack
+// it, and one XOR 0x80808080 per dword turns the four bytes back into int8.
+struct Rq {
+  float lo_f, hi_f, off;  // lo - zp, hi - zp, zp + 128
+};
+__host__ __device__ inline Rq make_rq(int zp, int lo, int hi) { return Rq{(float)(lo - zp), (float)(hi - zp), (float)(zp + 128)}; }
+__device__ __forceinline__ float rq_u8(float accf, float mult, const Rq& q) {
+  float r = __builtin_rintf(accf * mult);
+  return __builtin_amdgcn_fmed3f(r, q.lo_f, q.hi_f) + q.off;
+}
+__device__ __forceinline__ unsigned pack4_u8f(float a, float b, float c, float d) {  // -> int8 x4
+  unsigned v = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0);
+  v = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, v);
+  v = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, v);
+  v = __builtin_amdgcn_cvt_pk_u8_f32(d, 3, v);
+  return v ^ 0x80808080u;
+}
+__device__ __forceinline__ unsigned rq_pack_i(const v4i& acc, const int4& b, const float4& mu, const Rq& q) {
+  return pack4_u8f(rq_u8((float)(acc[0] + b.x), mu.x, q), rq_u8((float)(acc[1] + b.y), mu.y, q),
+                   rq_u8((float)(acc[2] + b.z), mu.z, q), rq_u8((float)(acc[3] + b.w), mu.w, q));
+}
+
 struct Epi {  // requantisation parameters of one conv
   const int* bias;    // folded bias, padded to NB*64
   const float* mult;  // padded to NB*64
   int zp, lo, hi;
+  Rq rq;
 };
 
 // Lane (r = lane&15 pixel, g = lane>>4) holds acc[t][j] = channel nb*64 + 16g + 4t + j of pixel r.
@@ -61,8 +86,7 @@ __device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_
   for (int t = 0; t < 4; t++) {
     int4 b = *(const int4*)(e.bias + c0 + 4 * t);
     float4 mu = *(const float4*)(e.mult + c0 + 4 * t);
-    d[t] = pack4(requant(acc[t][0] + b.x, mu.x, e.zp, e.lo, e.hi), requant(acc[t][1] + b.y, mu.y, e.zp, e.lo, e.hi),
-                 requant(acc[t][2] + b.z, mu.z, e.zp, e.lo, e.hi), requant(acc[t][3] + b.w, mu.w, e.zp, e.lo, e.hi));
+    d[t] = rq_pack_i(acc[t], b, mu, e.rq);
   }
   int8_t* o = out + m * N + c0;
   if ((N & 15) == 0) {
@@ -79,6 +103,8 @@ __device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_
         if (c0 + 4 * t + j < N) o[4 * t + j] = (int8_t)(d[t] >> (8 * j));
   }
 }
+
+#include "fused_block.h"  // (inside namespace vbt)
 
 // ------------------------------------------------------------------------------------------
 // pointwise conv, variant A: K <= 256, activations of 16*MS pixels stay in registers while the
@@ -278,9 +304,118 @@ __global__ __launch_bounds__(256) void dw_kernel(const int8_t* __restrict__ x, c
   for (int o = 0; o < R; o++) {
     int ox = ox0 + o;
     if (ox < OW) {
-      unsigned d = pack4(requant((int)acc[o][0] + bq.x, mu.x, e.zp, e.lo, e.hi), requant((int)acc[o][1] + bq.y, mu.y, e.zp, e.lo, e.hi),
-                         requant((int)acc[o][2] + bq.z, mu.z, e.zp, e.lo, e.hi), requant((int)acc[o][3] + bq.w, mu.w, e.zp, e.lo, e.hi));
+      v4i ai = {(int)acc[o][0], (int)acc[o][1], (int)acc[o][2], (int)acc[o][3]};
+      unsigned d = rq_pack_i(ai, bq, mu, e.rq);
       *(unsigned*)(ob + (long)ox * C) = d;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise conv, column walker: a lane owns 4 channels x 4 output columns and walks DOWN a segment of
+// output rows.  The k*k*4 weights stay in registers for the whole walk; every input row is loaded and
+// converted once and scattered into the (at most ceil(k/s)) output rows still in flight, which live in a
+// statically indexed accumulator ring (the row loop is unrolled by the ring period).
+// ------------------------------------------------------------------------------------------
+constexpr int cmod(int a, int n) { return ((a % n) + n) % n; }
+constexpr int cfloordiv(int a, int n) { return (a - cmod(a, n)) / n; }
+
+template <int KK, int S>
+__global__ __launch_bounds__(256) void dw_col_kernel(const int8_t* __restrict__ x, const float* __restrict__ wf, Epi e,
+                                                     int8_t* __restrict__ out, long total, int H, int W, int C, int OH, int OW,
+                                                     int pad_t, int pad_l, unsigned pad4, int rows, int nseg) {
+  constexpr int IW = 3 * S + KK;
+  constexpr int NS = (KK + S - 1) / S;
+  constexpr int P = NS * S;
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int C4 = C >> 2, XR = (OW + 3) >> 2;
+  const int c4 = (int)(idx % C4);
+  long t = idx / C4;
+  const int xr = (int)(t % XR);
+  t /= XR;
+  const int seg = (int)(t % nseg);
+  const long b = t / nseg;
+  const int oy_b = seg * rows;
+  const int nrows = min(rows, OH - oy_b);
+  if (nrows <= 0) return;
+  const int ox0 = xr * 4;
+  const int iy_b = oy_b * S - pad_t, ix_b = ox0 * S - pad_l;
+  const int n_in = (nrows - 1) * S + KK;
+  float4 w[KK][KK];
+#pragma unroll
+  for (int ky = 0; ky < KK; ky++)
+#pragma unroll
+    for (int kx = 0; kx < KK; kx++) w[ky][kx] = *(const float4*)(wf + (long)(ky * KK + kx) * C + 4 * c4);
+  const int4 bq = *(const int4*)(e.bias + 4 * c4);
+  const float4 mu = *(const float4*)(e.mult + 4 * c4);
+  float acc[NS][4][4];
+#pragma unroll
+  for (int sl = 0; sl < NS; sl++)
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[sl][o][j] = 0.0f;
+  unsigned colmask = 0;
+#pragma unroll
+  for (int j = 0; j < IW; j++)
+    if (ix_b + j >= 0 && ix_b + j < W) colmask |= 1u << j;
+  const int8_t* xb = x + b * (long)H * W * C + 4 * c4;
+  int8_t* ob = out + b * (long)OH * OW * C + 4 * c4;
+  for (int i0 = 0; i0 < n_in; i0 += P) {
+#pragma unroll
+    for (int r = 0; r < P; r++) {
+      const int i = i0 + r;
+      if (i >= n_in) break;
+      const int iy = iy_b + i;
+      const bool rowok = iy >= 0 && iy < H;
+      const int8_t* rp = xb + ((long)iy * W + ix_b) * C;
+      bool kyok[KK];
+#pragma unroll
+      for (int ky = 0; ky < KK; ky++) kyok[ky] = (i - ky) >= 0 && (i - ky) / S < nrows;
+#pragma unroll
+      for (int j = 0; j < IW; j++) {
+        unsigned u = pad4;
+        if (rowok && ((colmask >> j) & 1u)) u = *(const unsigned*)(rp + (long)j * C) ^ 0x80808080u;
+        const float f0 = (float)(u & 255u), f1 = (float)((u >> 8) & 255u), f2 = (float)((u >> 16) & 255u), f3 = (float)(u >> 24);
+#pragma unroll
+        for (int ky = 0; ky < KK; ky++) {
+          if (cmod(r - ky, S) == 0) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int sl = cmod(cfloordiv(r - ky, S), NS);
+            if (kyok[ky]) {
+#pragma unroll
+              for (int kx = 0; kx < KK; kx++) {
+                if ((j - kx) >= 0 && (j - kx) % S == 0 && (j - kx) / S < 4) {
+                  const int o = (j - kx) / S;
+                  acc[sl][o][0] = __builtin_fmaf(f0, w[ky][kx].x, acc[sl][o][0]);
+                  acc[sl][o][1] = __builtin_fmaf(f1, w[ky][kx].y, acc[sl][o][1]);
+                  acc[sl][o][2] = __builtin_fmaf(f2, w[ky][kx].z, acc[sl][o][2]);
+                  acc[sl][o][3] = __builtin_fmaf(f3, w[ky][kx].w, acc[sl][o][3]);
+                }
+              }
+            }
+          }
+        }
+      }
+      // the output row whose last input row this was
+      if (cmod(r - (KK - 1), S) == 0) {
+        const int sl = cmod(cfloordiv(r - (KK - 1), S), NS);
+        const int od = (i - (KK - 1)) / S;
+        if (i - (KK - 1) >= 0 && od < nrows) {
+          int8_t* orow = ob + ((long)(oy_b + od) * OW) * C;
+#pragma unroll
+          for (int o = 0; o < 4; o++) {
+            const v4i ai = {(int)acc[sl][o][0], (int)acc[sl][o][1], (int)acc[sl][o][2], (int)acc[sl][o][3]};
+            if (ox0 + o < OW) *(unsigned*)(orow + (long)(ox0 + o) * C) = rq_pack_i(ai, bq, mu, e.rq);
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[sl][o][j] = 0.0f;
+      }
     }
   }
 }
@@ -567,9 +702,9 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
-                                           "maxpool3x3s2", "resize_nn", "decode_nms"};
+                                           "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv"};
 
 struct Step {
   int op;       // index into ops
@@ -581,6 +716,23 @@ struct Step {
   float* mult = nullptr;   // multipliers (device, padded)
   int KS = 0, NB = 0;
   double alg_bytes_per_frame = 0, weight_bytes = 0, macs_per_frame = 0;
+  // fused block (F_MBCONV / F_SEPCONV): constituent op indices (-1 = absent) and kernel arguments
+  int e_op = -1, d_op = -1, p_op = -1, a_op = -1;
+  FusedArgs fa;
+  int nbp = 0, lds_bytes = 0;
+  int variant = -1;  // kernel variant chosen by the autotuner (-1 = heuristic default)
+};
+
+// A group of consecutive graph ops with alternative realisations (all bit-identical); the planner keeps
+// the fastest one measured on this device at this batch size.
+struct Alt {
+  std::vector<Step> steps;
+  std::vector<int> hidden;  // tensors that never reach HBM under this alternative
+  double ms = 0;
+};
+struct Group {
+  std::vector<Alt> alts;
+  int chosen = 0;
 };
 
 }  // namespace vbt
@@ -603,7 +755,11 @@ struct vbt_model {
   int* out_counts = nullptr;
   float* d_anchors = nullptr;
   float* d_luts = nullptr;
-  std::vector<Step> steps;
+  std::vector<Step> steps;      // execution list (after fusion + autotuning)
+  std::vector<Group> groups;
+  std::vector<Step> op_steps;   // one per graph op (weights live here)
+  std::vector<char> materialized;  // per tensor: written to HBM by the execution list
+  int flags = 0;
   std::vector<void*> owned;  // device allocations to free
   int last_B = 0;
 };
@@ -637,6 +793,208 @@ static void pack_weights(const int8_t* w, int N, int K, int KS, int NB, const st
             o[((((size_t)(nb * KS + ks) * 4 + t) * 64 + lane) * 8) + j] = v;
           }
         }
+}
+
+
+// ---- fusion pass: MBConv (pw+relu6 -> dw -> pw [-> add]) and SeparableConv (dw -> pw) -> fused_block_kernel ----
+static void choose_tile(int OH, int OW, int KK, int S, bool expand, int* TXo, int* TYo) {
+  double best = 1e300;
+  for (int TX = 1; TX <= std::min(OW, 64); TX++) {
+    int TXp = (TX + 3) & ~3;
+    int TY = std::min(OH, 64 / TXp);
+    if (TY < 1) continue;
+    int tiles = ((OW + TX - 1) / TX) * ((OH + TY - 1) / TY);
+    int NPh = ((TXp - 1) * S + KK) * ((TY - 1) * S + KK);
+    // halo pixels cost expand work + LDS loads; every tile also pays the 64-slot depthwise/project work
+    double cost = tiles * ((expand ? 1.0 : 0.35) * NPh + 64.0);
+    if (cost < best) { best = cost; *TXo = TX; *TYo = TY; }
+  }
+}
+
+static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step* out) {
+  const OpRec& dop = m->ops[d_op];
+  const OpRec& pop = m->ops[p_op];
+  const bool expand = e_op >= 0;
+  const int in_t = expand ? m->ops[e_op].inputs[0] : dop.inputs[0];
+  const TensorRec& tin = m->tensors[in_t];
+  const TensorRec& tdin = m->tensors[dop.inputs[0]];
+  const TensorRec& tdout = m->tensors[dop.output];
+  const TensorRec& tout = m->tensors[pop.output];
+  const int Ce = tdin.c, Cp = (Ce + 63) / 64 * 64, kk = dop.k * dop.k;
+  Step s;
+  s.family = expand ? F_MBCONV : F_SEPCONV;
+  s.op = a_op >= 0 ? a_op : p_op;  // the op whose output this step writes
+  s.e_op = e_op; s.d_op = d_op; s.p_op = p_op; s.a_op = a_op;
+  FusedArgs& a = s.fa;
+  memset(&a, 0, sizeof(a));
+  a.H = tin.h; a.W = tin.w; a.Cin = tin.c; a.OH = tout.h; a.OW = tout.w; a.Cout = tout.c;
+  a.pad_t = dop.pad_t; a.pad_l = dop.pad_l;
+  choose_tile(tout.h, tout.w, dop.k, dop.stride, expand, &a.TX, &a.TY);
+  a.tiles_x = (tout.w + a.TX - 1) / a.TX;
+  a.tiles_y = (tout.h + a.TY - 1) / a.TY;
+  a.nchunks = Cp / 64;
+  a.zx = tin.zero_point;
+  const Step& ds = m->op_steps[d_op];
+  const Step& ps = m->op_steps[p_op];
+  if (expand) {
+    const Step& es = m->op_steps[e_op];
+    const OpRec& eop = m->ops[e_op];
+    a.we = es.wp; a.be = es.bias; a.me = es.mult; a.KSe = es.KS;
+    a.ze = tdin.zero_point; a.loe = eop.act_min; a.hie = eop.act_max;
+    a.rqe = make_rq(a.ze, a.loe, a.hie);
+    a.T0S = es.KS * 32 + 8;
+  } else {
+    a.T0S = Cp + 16;
+  }
+  // depthwise parameters padded to Cp channels
+  {
+    const int8_t* w = (const int8_t*)(m->blob.data() + dop.w_off);
+    const int32_t* bq = (const int32_t*)(m->blob.data() + dop.b_off);
+    const float* mu = (const float*)(m->blob.data() + dop.m_off);
+    std::vector<float> wf((size_t)kk * Cp, 0.0f), mult(Cp, 0.0f);
+    std::vector<int> bias(Cp, 0);
+    for (int c = 0; c < Ce; c++) {
+      long sw = 0;
+      for (int t = 0; t < kk; t++) { wf[(size_t)t * Cp + c] = (float)w[(size_t)t * Ce + c]; sw += w[(size_t)t * Ce + c]; }
+      bias[c] = (int)((long)bq[c] - (long)(128 + tdin.zero_point) * sw);
+      mult[c] = mu[c];
+    }
+    float* dwf; int* dbias; float* dmult;
+    int rc;
+    if ((rc = upload(m, wf, &dwf)) || (rc = upload(m, bias, &dbias)) || (rc = upload(m, mult, &dmult))) return rc;
+    a.wd = dwf; a.bd = dbias; a.md = dmult;
+    a.zd = tdout.zero_point; a.lod = dop.act_min; a.hid = dop.act_max;
+    a.rqd = make_rq(a.zd, a.lod, a.hid);
+  }
+  // project weights re-packed with K padded to Cp
+  {
+    const int8_t* w = (const int8_t*)(m->blob.data() + pop.w_off);
+    std::vector<long> wp;
+    pack_weights(w, tout.c, Ce, Cp / 32, ps.NB, nullptr, wp);
+    long* dwp;
+    int rc;
+    if ((rc = upload(m, wp, &dwp))) return rc;
+    a.wp = dwp; a.bp = ps.bias; a.mp = ps.mult; a.KSp = Cp / 32;
+    a.zo = tout.zero_point; a.lop = pop.act_min; a.hip = pop.act_max;
+    a.rqp = make_rq(a.zo, a.lop, a.hip);
+  }
+  if (a_op >= 0) {
+    const OpRec& aop = m->ops[a_op];
+    const TensorRec& tr = m->tensors[aop.output];
+    a.has_res = 1; a.ka = aop.in_mult[0]; a.kb = aop.in_mult[1];
+    a.zr = tr.zero_point; a.lor = aop.act_min; a.hir = aop.act_max;
+  }
+  s.nbp = ps.NB <= 3 ? ps.NB : 5;
+  const int TXp = (a.TX + 3) & ~3;
+  const int NPh = ((TXp - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
+  s.lds_bytes = ((NPh * a.T0S + 15) & ~15) + (expand ? NPh * FB_EST : 0) + 64 * FB_DST;
+  // accounting = compulsory traffic of the constituent graph ops
+  for (int oi : {e_op, d_op, p_op, a_op})
+    if (oi >= 0) {
+      s.alg_bytes_per_frame += m->op_steps[oi].alg_bytes_per_frame;
+      s.weight_bytes += m->op_steps[oi].weight_bytes;
+      s.macs_per_frame += m->op_steps[oi].macs_per_frame;
+    }
+  *out = s;
+  return VBT_OK;
+}
+
+static int fuse_plan(vbt_model* m) {
+  const int no = (int)m->ops.size();
+  std::vector<int> consumers(m->tensors.size(), 0);
+  for (const OpRec& op : m->ops)
+    for (int i = 0; i < op.n_inputs; i++) consumers[op.inputs[i]]++;
+  const bool fuse_mb = !(m->flags & 1) && !(m->flags & 2);
+  const bool fuse_sep = !(m->flags & 1) && !(m->flags & 4);
+  auto dw_ok = [&](const OpRec& d) { return (d.k == 3 || d.k == 5) && (d.stride == 1 || d.stride == 2); };
+  auto sep_ok = [&](int di) {
+    if (di + 1 >= no) return false;
+    const OpRec& d = m->ops[di];
+    const OpRec& p = m->ops[di + 1];
+    return d.type == OP_DW && dw_ok(d) && p.type == OP_PW && p.inputs[0] == d.output && consumers[d.output] == 1 &&
+           m->tensors[d.inputs[0]].c % 8 == 0 && (m->tensors[p.output].c + 63) / 64 <= 5;
+  };
+  for (int i = 0; i < no;) {
+    const OpRec& op = m->ops[i];
+    Group g;
+    int span = 1;
+    bool mb = op.type == OP_PW && i + 2 < no && m->ops[i + 1].inputs[0] == op.output && consumers[op.output] == 1 && sep_ok(i + 1) &&
+              m->tensors[op.inputs[0]].c % 8 == 0;
+    if (mb && (fuse_mb || fuse_sep)) {
+      const OpRec& d = m->ops[i + 1];
+      const OpRec& p = m->ops[i + 2];
+      int a_op = -1;
+      if (i + 3 < no) {
+        const OpRec& ad = m->ops[i + 3];
+        if (ad.type == OP_ADD && ad.n_inputs == 2 && ad.inputs[0] == p.output && ad.inputs[1] == op.inputs[0] &&
+            consumers[p.output] == 1 && d.stride == 1 && m->tensors[op.inputs[0]].c == m->tensors[p.output].c)
+          a_op = i + 3;
+      }
+      span = a_op >= 0 ? 4 : 3;
+      Alt unf;
+      for (int k = 0; k < span; k++) unf.steps.push_back(m->op_steps[i + k]);
+      g.alts.push_back(unf);
+      if (fuse_sep) {  // expand as its own kernel, dw+project(+add) fused
+        Alt a2;
+        a2.steps.push_back(m->op_steps[i]);
+        Step s;
+        int rc = make_fused(m, -1, i + 1, i + 2, -1, &s);  // residual stays a separate ADD (its skip input is not in T0)
+        if (rc) return rc;
+        if (s.lds_bytes <= 64 * 1024) {
+          a2.steps.push_back(s);
+          a2.hidden.push_back(d.output);
+          if (a_op >= 0) a2.steps.push_back(m->op_steps[a_op]);
+          g.alts.push_back(a2);
+        }
+      }
+      if (fuse_mb) {
+        Alt a3;
+        Step s;
+        int rc = make_fused(m, i, i + 1, i + 2, a_op, &s);
+        if (rc) return rc;
+        if (s.lds_bytes <= 64 * 1024) {
+          a3.steps.push_back(s);
+          a3.hidden.push_back(op.output);
+          a3.hidden.push_back(d.output);
+          if (a_op >= 0) a3.hidden.push_back(p.output);
+          g.alts.push_back(a3);
+        }
+      }
+    } else if (fuse_sep && sep_ok(i)) {
+      span = 2;
+      Alt unf;
+      unf.steps.push_back(m->op_steps[i]);
+      unf.steps.push_back(m->op_steps[i + 1]);
+      g.alts.push_back(unf);
+      Alt a2;
+      Step s;
+      int rc = make_fused(m, -1, i, i + 1, -1, &s);
+      if (rc) return rc;
+      if (s.lds_bytes <= 64 * 1024) {
+        a2.steps.push_back(s);
+        a2.hidden.push_back(op.output);
+        g.alts.push_back(a2);
+      }
+    } else {
+      Alt unf;
+      unf.steps.push_back(m->op_steps[i]);
+      g.alts.push_back(unf);
+    }
+    g.chosen = (int)g.alts.size() - 1;  // without autotuning: the most fused alternative
+    m->groups.push_back(g);
+    i += span;
+  }
+  return VBT_OK;
+}
+
+static void finalize_plan(vbt_model* m) {
+  m->steps.clear();
+  m->materialized.assign(m->tensors.size(), 1);
+  for (const Group& g : m->groups) {
+    const Alt& a = g.alts[g.chosen];
+    for (const Step& s : a.steps) m->steps.push_back(s);
+    for (int t : a.hidden) m->materialized[t] = 0;
+  }
 }
 
 static int build_plan(vbt_model* m) {
@@ -730,9 +1088,9 @@ static int build_plan(vbt_model* m) {
       set_error("unknown op type %d", op.type);
       return VBT_ERR_ARG;
     }
-    m->steps.push_back(s);
+    m->op_steps.push_back(s);
   }
-  return VBT_OK;
+  return fuse_plan(m);
 }
 
 template <int KS>
@@ -747,7 +1105,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
   const OpRec& op = m->ops[s.op];
   const TensorRec& to = m->tensors[op.output];
   int8_t* out = m->tptr[op.output];
-  Epi e{s.bias, s.mult, to.zero_point, op.act_min, op.act_max};
+  Epi e{s.bias, s.mult, to.zero_point, op.act_min, op.act_max, make_rq(to.zero_point, op.act_min, op.act_max)};
   switch (s.family) {
     case F_STEM: {
       const TensorRec& ti = m->tensors[op.inputs[0]];
@@ -762,7 +1120,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       long M = (long)B * to.h * to.w;
       int K = ti.c, N = to.c;
       if (s.KS <= 8) {
-        int MS = M >= 32768 ? 2 : 1;
+        int MS = s.variant >= 0 ? (s.variant & 1) + 1 : (M >= 32768 ? 2 : 1);
         long waves = (M + 16 * MS - 1) / (16 * MS);
         unsigned gx = (unsigned)((waves + 3) / 4);
         int ysplit = 1;
@@ -800,16 +1158,32 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const TensorRec& ti = m->tensors[op.inputs[0]];
       const int8_t* x = m->tptr[op.inputs[0]];
       int C = to.c;
-      long total = (long)B * to.h * ((to.w + 3) / 4) * (C / 4);
-      dim3 grid((unsigned)((total + 255) / 256));
       unsigned pb = (unsigned)((128 + ti.zero_point) & 255);
       unsigned pad4 = pb | (pb << 8) | (pb << 16) | (pb << 24);
+      if (s.variant == 0) {  // one output row x 4 columns per lane
+        long total = (long)B * to.h * ((to.w + 3) / 4) * (C / 4);
+        dim3 grid((unsigned)((total + 255) / 256));
 #define DW_LAUNCH(KK, S) dw_kernel<KK, S><<<grid, 256, 0, st>>>(x, s.wf, e, out, total, ti.h, ti.w, C, to.h, to.w, op.pad_t, op.pad_l, pad4)
-      if (op.k == 3 && op.stride == 1) DW_LAUNCH(3, 1);
-      else if (op.k == 3 && op.stride == 2) DW_LAUNCH(3, 2);
-      else if (op.k == 5 && op.stride == 1) DW_LAUNCH(5, 1);
-      else DW_LAUNCH(5, 2);
+        if (op.k == 3 && op.stride == 1) DW_LAUNCH(3, 1);
+        else if (op.k == 3 && op.stride == 2) DW_LAUNCH(3, 2);
+        else if (op.k == 5 && op.stride == 1) DW_LAUNCH(5, 1);
+        else DW_LAUNCH(5, 2);
 #undef DW_LAUNCH
+      } else {               // column walker, `rows` output rows per lane
+        const int XR = (to.w + 3) / 4;
+        long per_seg = (long)B * XR * (C / 4);
+        int rows = s.variant > 0 ? s.variant : (int)std::min<long>(std::max<long>(to.h * per_seg / 400000, 1), 16);
+        rows = std::min(rows, to.h);
+        int nseg = (to.h + rows - 1) / rows;
+        long total = per_seg * nseg;
+        dim3 grid((unsigned)((total + 255) / 256));
+#define DW_LAUNCH(KK, S) dw_col_kernel<KK, S><<<grid, 256, 0, st>>>(x, s.wf, e, out, total, ti.h, ti.w, C, to.h, to.w, op.pad_t, op.pad_l, pad4, rows, nseg)
+        if (op.k == 3 && op.stride == 1) DW_LAUNCH(3, 1);
+        else if (op.k == 3 && op.stride == 2) DW_LAUNCH(3, 2);
+        else if (op.k == 5 && op.stride == 1) DW_LAUNCH(5, 1);
+        else DW_LAUNCH(5, 2);
+#undef DW_LAUNCH
+      }
       break;
     }
     case F_ADD: {
@@ -840,6 +1214,36 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
                                                                             to.h, to.w);
       break;
     }
+    case F_MBCONV:
+    case F_SEPCONV: {
+      FusedArgs a = s.fa;
+      a.x = s.e_op >= 0 ? m->tptr[m->ops[s.e_op].inputs[0]] : m->tptr[m->ops[s.d_op].inputs[0]];
+      a.out = out;
+      const OpRec& dop = m->ops[s.d_op];
+      dim3 grid((unsigned)((long)B * a.tiles_x * a.tiles_y));
+      const bool ex = s.family == F_MBCONV;
+#define FB_LAUNCH(KK, S, NBP)                                                                              \
+  do {                                                                                                     \
+    if (ex) fused_block_kernel<KK, S, NBP, true><<<grid, 256, s.lds_bytes, st>>>(a);                        \
+    else fused_block_kernel<KK, S, NBP, false><<<grid, 256, s.lds_bytes, st>>>(a);                          \
+  } while (0)
+#define FB_NBP(KK, S)                                      \
+  do {                                                     \
+    switch (s.nbp) {                                       \
+      case 1: FB_LAUNCH(KK, S, 1); break;                  \
+      case 2: FB_LAUNCH(KK, S, 2); break;                  \
+      case 3: FB_LAUNCH(KK, S, 3); break;                  \
+      default: FB_LAUNCH(KK, S, 5); break;                 \
+    }                                                      \
+  } while (0)
+      if (dop.k == 3 && dop.stride == 1) FB_NBP(3, 1);
+      else if (dop.k == 3 && dop.stride == 2) FB_NBP(3, 2);
+      else if (dop.k == 5 && dop.stride == 1) FB_NBP(5, 1);
+      else FB_NBP(5, 2);
+#undef FB_NBP
+#undef FB_LAUNCH
+      break;
+    }
     case F_POST: {
       PostArgs p;
       int base = 0;
@@ -866,6 +1270,62 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
     }
   }
   return VBT_OK;
+}
+
+static double time_step(vbt_model* m, const Step& s, int B, int reps) {
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1e30;
+  launch_step(m, s, B, nullptr, m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+  (void)hipEventRecord(e0, nullptr);
+  for (int r = 0; r < reps; r++)
+    launch_step(m, s, B, nullptr, m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+  (void)hipEventRecord(e1, nullptr);
+  float ms = 1e30f;
+  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ms / reps;
+}
+
+// Plan-time autotuning: every alternative computes bit-identical tensors, so only speed is at stake.
+static void autotune(vbt_model* m) {
+  const int B = m->max_batch, reps = 4;
+  for (Group& g : m->groups) {
+    bool single = g.alts.size() == 1 && g.alts[0].steps.size() == 1;
+    if (single) {
+      int f = g.alts[0].steps[0].family;
+      if (f != F_DW && f != F_PW) continue;  // nothing to choose
+    }
+    for (Alt& a : g.alts) {
+      a.ms = 0;
+      for (Step& st : a.steps) {
+        std::vector<int> cand{-1};
+        const OpRec& op = m->ops[st.op];
+        if (st.family == F_DW) {
+          cand = {0};
+          for (int r : {1, 2, 4, 8, 16})
+            if (r <= m->tensors[op.output].h) cand.push_back(r);
+        } else if (st.family == F_PW && st.KS <= 8) {
+          cand = {0, 1};
+        }
+        double best = 1e30;
+        int bestv = -1;
+        for (int v : cand) {
+          Step t = st;
+          t.variant = v;
+          double ms = time_step(m, t, B, reps);
+          if (ms < best) { best = ms; bestv = v; }
+        }
+        st.variant = bestv;
+        a.ms += best;
+      }
+    }
+    int bi = 0;
+    for (size_t i = 1; i < g.alts.size(); i++)
+      if (g.alts[i].ms < g.alts[bi].ms) bi = (int)i;
+    g.chosen = bi;
+  }
+  (void)hipDeviceSynchronize();
 }
 
 static int enqueue_forward(vbt_model* m, const uint8_t* frames_dev, int B, hipStream_t st, float* boxes, float* scores,
@@ -899,6 +1359,18 @@ int vbt_device_count(void) {
 }
 
 int vbt_model_create(const char* path, int device, int max_batch, vbt_model** out) {
+  const char* nf = getenv("VBT_FUSION_FLAGS");  // bit0: no fusion, bit1: no MBConv fusion, bit2: no SeparableConv fusion
+  return vbt_model_create_ex(path, device, max_batch, nf ? atoi(nf) : VBT_MODEL_DEFAULT_FLAGS, out);
+}
+
+int vbt_model_tensor_materialized(const vbt_model* m, int id) {
+  if (!m || id < 0 || id >= (int)m->tensors.size()) { set_error("bad tensor id"); return VBT_ERR_ARG; }
+  return m->materialized[id] ? 1 : 0;
+}
+
+int vbt_model_num_launches(const vbt_model* m) { return m ? (int)m->steps.size() : VBT_ERR_ARG; }
+
+int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, vbt_model** out) {
   if (!path || !out || max_batch < 1) { set_error("vbt_model_create: bad argument"); return VBT_ERR_ARG; }
   *out = nullptr;
   FILE* f = fopen(path, "rb");
@@ -918,6 +1390,7 @@ int vbt_model_create(const char* path, int device, int max_batch, vbt_model** ou
   if (!ok) { delete m; set_error("'%s' is not a valid VBTM container", path); return VBT_ERR_IO; }
   m->device = device;
   m->max_batch = max_batch;
+  m->flags = flags;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
     delete m;
@@ -957,6 +1430,8 @@ int vbt_model_create(const char* path, int device, int max_batch, vbt_model** ou
       std::vector<float> lut((const float*)(m->blob.data() + op.aux2_off), (const float*)(m->blob.data() + op.aux2_off) + 768);
       if ((rc = upload(m, an, &m->d_anchors)) || (rc = upload(m, lut, &m->d_luts))) return fail(rc);
     }
+  if (!(m->flags & VBT_MODEL_NO_AUTOTUNE)) autotune(m);
+  finalize_plan(m);
   *out = m;
   return VBT_OK;
 }
@@ -1020,6 +1495,7 @@ int vbt_detect(vbt_model* m, const uint8_t* frames, int B, int frames_on_device,
 int vbt_model_read_tensor(vbt_model* m, int id, int B, int8_t* host_out) {
   if (!m || !host_out || id < 0 || id >= (int)m->tensors.size() || id == m->hdr.input_tensor) { set_error("bad tensor id"); return VBT_ERR_ARG; }
   if (B < 1 || B > m->max_batch) { set_error("bad batch"); return VBT_ERR_CAPACITY; }
+  if (!m->materialized[id]) { set_error("tensor %d lives only in LDS (fused away); create the model with VBT_MODEL_NO_FUSION to read it", id); return VBT_ERR_STATE; }
   VBT_HIP_CHECK(hipDeviceSynchronize());
   VBT_HIP_CHECK(hipMemcpy(host_out, m->tptr[id], m->telems[id] * B, hipMemcpyDeviceToHost));
   return VBT_OK;

@@ -1,0 +1,249 @@
+// Fused block kernel: [expand 1x1 + ReLU6 ->] depthwise kxk (stride 1|2) -> project 1x1 [-> residual ADD]
+// on LDS-resident tiles.  Included by detector.hip after the requantisation helpers.
+//
+// Covers (a) every MBConv block of the EfficientNet-Lite backbone (the 6x expanded tensor and the
+// depthwise output never touch HBM) and, with EXPAND = false, (b) every SeparableConv of the BiFPN and
+// of the box/class heads (dw3x3 -> pw1x1).  Results are bit-identical to running the constituent graph
+// ops one by one (same integer accumulations, same single-op float requantisation).
+//
+// One workgroup (4 wavefronts) = one output tile of <= 64 pixels of one image:
+//   T0  [NPh][T0S]   input halo tile (int8 NHWC rows), out-of-image pixels = input zero point
+//   E   [NPh][80]    one 64-channel chunk of the expanded tensor on the halo (EXPAND only)
+//   D   [64][72]     one 64-channel chunk of the depthwise output
+// per 64-channel chunk: expand (int8 MFMA, all halo pixels; out-of-image halo pixels are forced to the
+// zero point of E because the depthwise pads ITS input) -> barrier -> depthwise (lane = 4 channels x 4
+// output columns, weights in registers, cvt_f32_ubyte + fma, exact) -> barrier -> project accumulation
+// (int8 MFMA, wave w owns pixels 16w..16w+15, accumulators stay in registers across chunks).
+#pragma once
+
+struct FusedArgs {
+  const int8_t* x;
+  int8_t* out;
+  int H, W, Cin, OH, OW, Cout;
+  int pad_t, pad_l;
+  int TX, TY, tiles_x, tiles_y;
+  int T0S;       // bytes per halo pixel row in LDS
+  int nchunks;   // Ce_pad / 64
+  int zx;        // zero point of the block input
+  // expand (EXPAND only)
+  const long* we;
+  const int* be;
+  const float* me;
+  int KSe, ze, loe, hie;
+  Rq rqe;
+  // depthwise
+  const float* wd;  // [k*k][Ce_pad]
+  const int* bd;    // folded, padded to Ce_pad
+  const float* md;
+  int zd, lod, hid;
+  Rq rqd;
+  // project
+  const long* wp;   // packed, K = Ce_pad
+  const int* bp;
+  const float* mp;
+  int KSp, zo, lop, hip;
+  Rq rqp;
+  // residual ADD (out = clamp(rne((q - zo)*ka + (x - zx)*kb) + zr))
+  int has_res;
+  float ka, kb;
+  int zr, lor, hir;
+};
+
+constexpr int FB_EST = 80;  // E tile bytes per pixel (64 + 16: bank spread, 16-B aligned)
+constexpr int FB_DST = 72;  // D tile bytes per pixel
+
+template <int KK, int S, int NBP, bool EXPAND>
+__global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  int tile = blockIdx.x;
+  const int tx = tile % a.tiles_x;
+  tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y;
+  const long b = tile / a.tiles_y;
+  const int oy0 = ty * a.TY, ox0 = tx * a.TX;
+  const int TXp = (a.TX + 3) & ~3;
+  const int HWx = (TXp - 1) * S + KK, HWy = (a.TY - 1) * S + KK, NPh = HWx * HWy;
+  const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
+  unsigned char* T0 = fb_smem;
+  unsigned char* E = T0 + ((NPh * a.T0S + 15) & ~15);
+  unsigned char* D = E + (EXPAND ? NPh * FB_EST : 0);
+
+  // ---- stage L: input halo tile -> LDS (8-byte granules, coalesced along channels) ----
+  {
+    const int ng = a.Cin >> 3;
+    const int total = NPh * ng;
+    const unsigned long long zb = (unsigned long long)(a.zx & 255) * 0x0101010101010101ull;
+    const int8_t* xb = a.x + b * (long)a.H * a.W * a.Cin;
+    for (int gi = tid; gi < total; gi += 256) {
+      int p = gi / ng, sg = gi - p * ng;
+      int hy = p / HWx, hx = p - hy * HWx;
+      int iy = iy0 + hy, ix = ix0 + hx;
+      unsigned long long v = zb;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const unsigned long long*)(xb + ((long)iy * a.W + ix) * a.Cin + 8 * sg);
+      *(unsigned long long*)(T0 + p * a.T0S + 8 * sg) = v;
+    }
+  }
+  // which of this wave's halo pixel groups hold out-of-image pixels (expand epilogue), bit i <-> pg = wave + 4i
+  const int NPG = (NPh + 15) >> 4;
+  unsigned oob_mask = 0, tail_mask = 0;
+  if (EXPAND) {
+    for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
+      int p = pg * 16 + r;
+      int pc = min(p, NPh - 1);
+      int hy = pc / HWx, hx = pc - hy * HWx;
+      int iy = iy0 + hy, ix = ix0 + hx;
+      if (!(iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)) oob_mask |= 1u << i;
+      if (p >= NPh) tail_mask |= 1u << i;
+    }
+  }
+  v4i acc[NBP][4];
+#pragma unroll
+  for (int nb = 0; nb < NBP; nb++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[nb][t] = (v4i){0, 0, 0, 0};
+  // depthwise lane geometry
+  const int cq = tid & 15, strip = tid >> 4;
+  const int nsx = TXp >> 2;
+  const int sy = strip / nsx, sx = (strip - sy * nsx) * 4;
+  const bool dw_active = sy < a.TY;
+  __syncthreads();
+
+  for (int c = 0; c < a.nchunks; c++) {
+    if (EXPAND) {
+      // ---- stage E: expand chunk c on every halo pixel ----
+      int4 eb[4];
+      float4 em[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        eb[t] = *(const int4*)(a.be + c * 64 + 16 * g + 4 * t);
+        em[t] = *(const float4*)(a.me + c * 64 + 16 * g + 4 * t);
+      }
+      const unsigned zeb = (unsigned)(a.ze & 255) * 0x01010101u;
+      for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
+        const int p = pg * 16 + r;
+        const int pc = min(p, NPh - 1);
+        v4i ea[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) ea[t] = (v4i){0, 0, 0, 0};
+        const unsigned char* brow = T0 + pc * a.T0S + 8 * g;
+        const long* w = a.we + (long)c * a.KSe * 4 * 64 + lane;
+        for (int ks = 0; ks < a.KSe; ks++) {
+          long bv = *(const long*)(brow + 32 * ks);
+#pragma unroll
+          for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[(ks * 4 + t) * 64], bv, ea[t], 0, 0, 0);
+        }
+        unsigned d[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          d[t] = rq_pack_i(ea[t], eb[t], em[t], a.rqe);
+        if ((oob_mask >> i) & 1u) { d[0] = zeb; d[1] = zeb; d[2] = zeb; d[3] = zeb; }
+        if (!((tail_mask >> i) & 1u)) *(uint4*)(E + p * FB_EST + 16 * g) = make_uint4(d[0], d[1], d[2], d[3]);
+      }
+      __syncthreads();
+    }
+    // ---- stage D: depthwise on chunk c ----
+    if (dw_active) {
+      const unsigned char* Ein = EXPAND ? E + 4 * cq : T0 + 64 * c + 4 * cq;
+      const int est = EXPAND ? FB_EST : a.T0S;
+      constexpr int IW = 3 * S + KK;
+      const int Cp = a.nchunks * 64;
+      const float* wd = a.wd + c * 64 + 4 * cq;
+      float dacc[4][4];
+#pragma unroll
+      for (int o = 0; o < 4; o++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) dacc[o][j] = 0.0f;
+#pragma unroll
+      for (int ky = 0; ky < KK; ky++) {
+        float4 wr[KK];
+#pragma unroll
+        for (int kx = 0; kx < KK; kx++) wr[kx] = *(const float4*)(wd + (long)(ky * KK + kx) * Cp);
+        const unsigned char* rowp = Ein + ((sy * S + ky) * HWx + sx * S) * est;
+#pragma unroll
+        for (int j = 0; j < IW; j++) {
+          unsigned u = *(const unsigned*)(rowp + j * est) ^ 0x80808080u;
+          float f0 = (float)(u & 255u), f1 = (float)((u >> 8) & 255u), f2 = (float)((u >> 16) & 255u), f3 = (float)(u >> 24);
+#pragma unroll
+          for (int kx = 0; kx < KK; kx++) {
+            if ((j - kx) >= 0 && (j - kx) % S == 0 && (j - kx) / S < 4) {
+              const int o = (j - kx) / S;
+              dacc[o][0] = __builtin_fmaf(f0, wr[kx].x, dacc[o][0]);
+              dacc[o][1] = __builtin_fmaf(f1, wr[kx].y, dacc[o][1]);
+              dacc[o][2] = __builtin_fmaf(f2, wr[kx].z, dacc[o][2]);
+              dacc[o][3] = __builtin_fmaf(f3, wr[kx].w, dacc[o][3]);
+            }
+          }
+        }
+      }
+      const int4 bq = *(const int4*)(a.bd + c * 64 + 4 * cq);
+      const float4 mu = *(const float4*)(a.md + c * 64 + 4 * cq);
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        v4i ai = {(int)dacc[o][0], (int)dacc[o][1], (int)dacc[o][2], (int)dacc[o][3]};
+        unsigned dd = rq_pack_i(ai, bq, mu, a.rqd);
+        *(unsigned*)(D + (sy * TXp + sx + o) * FB_DST + 4 * cq) = dd;
+      }
+    }
+    __syncthreads();
+    // ---- stage P: project accumulation, wave w <- pixel slots 16w..16w+15, K = this chunk's 64 channels ----
+#pragma unroll
+    for (int k2 = 0; k2 < 2; k2++) {
+      long bv = *(const long*)(D + (wave * 16 + r) * FB_DST + 32 * k2 + 8 * g);
+#pragma unroll
+      for (int nb = 0; nb < NBP; nb++) {
+        const long* w = a.wp + ((long)(nb * a.KSp + 2 * c + k2) * 4) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[nb][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], bv, acc[nb][t], 0, 0, 0);
+      }
+    }
+    if (!EXPAND && c + 1 < a.nchunks) __syncthreads();  // D is rewritten by the next chunk's depthwise
+  }
+
+  // ---- epilogue: requantise, optional residual ADD with the block input (centre of T0), store ----
+  const int slot = wave * 16 + r;
+  const int py = slot / TXp, px = slot - py * TXp;
+  const int oy = oy0 + py, ox = ox0 + px;
+  if (py < a.TY && px < a.TX && oy < a.OH && ox < a.OW) {
+    const unsigned char* skip = T0 + ((py + a.pad_t) * HWx + (px + a.pad_l)) * a.T0S;  // S == 1 when has_res
+    int8_t* orow = a.out + ((b * a.OH + oy) * (long)a.OW + ox) * a.Cout;
+#pragma unroll
+    for (int nb = 0; nb < NBP; nb++) {
+      const int c0 = nb * 64 + 16 * g;
+      if (c0 >= a.Cout) continue;
+      unsigned d[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        int4 bb = *(const int4*)(a.bp + c0 + 4 * t);
+        float4 mu = *(const float4*)(a.mp + c0 + 4 * t);
+        unsigned dq = rq_pack_i(acc[nb][t], bb, mu, a.rqp);
+        int q[4] = {(int)(int8_t)(dq & 255u), (int)(int8_t)((dq >> 8) & 255u), (int)(int8_t)((dq >> 16) & 255u), (int)(int8_t)(dq >> 24)};
+        if (a.has_res) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            int xs = (int)(int8_t)skip[min(c0 + 4 * t + j, a.Cin - 1)];
+            float rr = (float)(q[j] - a.zo) * a.ka;
+            rr = __builtin_fmaf((float)(xs - a.zx), a.kb, rr);
+            int v = (int)__builtin_rintf(rr) + a.zr;
+            q[j] = min(max(v, a.lor), a.hir);
+          }
+        }
+        d[t] = a.has_res ? pack4(q[0], q[1], q[2], q[3]) : dq;
+      }
+      int8_t* o = orow + c0;
+      if ((a.Cout & 15) == 0) {
+        *(uint4*)o = make_uint4(d[0], d[1], d[2], d[3]);
+      } else if ((a.Cout & 3) == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          if (c0 + 4 * t < a.Cout) *(unsigned*)(o + 4 * t) = d[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (c0 + 4 * t + j < a.Cout) o[4 * t + j] = (int8_t)(d[t] >> (8 * j));
+      }
+    }
+  }
+}

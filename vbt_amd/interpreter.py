@@ -7,6 +7,7 @@ Mirrors the slice of tflite_runtime.interpreter.Interpreter the reference uses:
   .get_signature_runner()(images=uint8[1,H,W,3]) -> {'output_0'..'output_3'}   reference odt.py:58-66
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -16,22 +17,23 @@ MAXDET = 25
 
 
 class Interpreter:
-    def __init__(self, model_path, num_threads=4, device=0, max_batch=1):
+    def __init__(self, model_path, num_threads=4, device=0, max_batch=1, fuse=True, flags=None):
         # num_threads is accepted for signature compatibility (reference track.py:72); the GPU path ignores it.
         self.model_path = str(model_path)
         self.num_threads = num_threads
         self.device = device
         self.max_batch = int(max_batch)
         self._h = ctypes.c_void_p()
-        _lib.check(_lib.lib().vbt_model_create(self.model_path.encode(), device, self.max_batch, ctypes.byref(self._h)))
+        _lib.check(_lib.lib().vbt_model_create_ex(self.model_path.encode(), device, self.max_batch, (flags if flags is not None else (int(os.environ.get('VBT_FUSION_FLAGS', '0')) if fuse else 1)),
+                                                  ctypes.byref(self._h)))
         shp = (ctypes.c_int * 4)()
         _lib.check(_lib.lib().vbt_model_input_shape(self._h, shp))
         self._shape = np.array([1, shp[1], shp[2], shp[3]], dtype=np.int32)
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            _lib.lib().vbt_model_destroy(h)
+        if h and _lib is not None and _lib._lib is not None:
+            _lib._lib.vbt_model_destroy(h)
             self._h = None
 
     @property
@@ -70,6 +72,12 @@ class Interpreter:
     # --- parity/debug helpers -------------------------------------------------
     def num_tensors(self):
         return _lib.lib().vbt_model_num_tensors(self._h)
+
+    def materialized(self, tid):
+        return bool(_lib.lib().vbt_model_tensor_materialized(self._h, tid))
+
+    def num_launches(self):
+        return _lib.lib().vbt_model_num_launches(self._h)
 
     def read_tensor(self, tid, B):
         shp = (ctypes.c_int * 3)()
