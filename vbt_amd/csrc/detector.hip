@@ -1324,6 +1324,17 @@ static void autotune(vbt_model* m) {
     for (size_t i = 1; i < g.alts.size(); i++)
       if (g.alts[i].ms < g.alts[bi].ms) bi = (int)i;
     g.chosen = bi;
+    if (getenv("VBT_AUTOTUNE_VERBOSE")) {
+      const Step& f = g.alts[0].steps[0];
+      const TensorRec& to = m->tensors[m->ops[g.alts[0].steps.back().op].output];
+      fprintf(stderr, "[autotune] op %3d.. out %3dx%3dx%4d :", f.op, to.h, to.w, to.c);
+      for (size_t i = 0; i < g.alts.size(); i++) {
+        fprintf(stderr, " alt%zu%s %.1fus(", i, (int)i == bi ? "*" : "", g.alts[i].ms * 1e3);
+        for (const Step& st : g.alts[i].steps) fprintf(stderr, "%s:v%d ", kFamilyName[st.family], st.variant);
+        fprintf(stderr, ")");
+      }
+      fprintf(stderr, "\n");
+    }
   }
   (void)hipDeviceSynchronize();
 }
