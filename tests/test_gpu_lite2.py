@@ -1,0 +1,53 @@
+"""BASELINE config 4: EfficientDet-Lite2 448x448 + OC-SORT association, 1x MI355X.
+The Lite2 container is generated on the fly (tools/make_model.py, seeded) into a temp dir and read by both
+the oracle and the HIP library, so nothing large is committed; the kernels and the planner are generic in
+(image size, widths, depths, BiFPN width/cells)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lite2_model(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("models") / "efficientdet_lite2_synth.vbtm")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_model.py"), "--arch", "2", "--out", out, "--calib", "4"])
+    return out
+
+
+def test_lite2_detector_and_tracker_parity(oracle_lib, lite2_model):
+    import torch
+    from oracle import ocsort_np
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    n, T, S = 2, 5, 448
+    frames = np.stack([np.stack([synth.render(synth.background(70 + c, S), 6 * c + t) for c in range(n)]) for t in range(T)])
+    det = oracle_lib.OracleDetector(lite2_model)
+    assert det.size == 448
+    pipe = Pipeline(lite2_model, n, max_frames=T, fps=30.0)
+    assert tuple(pipe.interpreter.get_input_details()[0]["shape"]) == (1, 448, 448, 3)
+    fd = torch.from_numpy(frames).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    got = []
+    for t in range(T):
+        pipe.step(fd[t].data_ptr(), st)
+        got.append(pipe.detections())
+    ob, os_, oc, on = oracle_lib.run_batch(lite2_model, frames.reshape(-1, S, S, 3), threads=8)
+    ob, os_, on = ob.reshape(T, n, 25, 4), os_.reshape(T, n, 25), on.reshape(T, n)
+    for t in range(T):
+        b, s, c, k = got[t]
+        assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t]), t
+    for c in range(n):
+        dets = [np.asarray([[ob[t, c, i, 1], ob[t, c, i, 0], ob[t, c, i, 3], ob[t, c, i, 2], os_[t, c, i], 0.0]
+                            for i in range(on[t, c]) if os_[t, c, i] >= 0.5], np.float64).reshape(-1, 6) for t in range(T)]
+        want = ocsort_np.track_boxes(dets, [(t + 1) / 30.0 for t in range(T)])
+        g = pipe.rows(c)
+        assert g["id"] == want["id"]
+        for k in ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width"):
+            assert np.array_equal(np.asarray(g[k]), np.asarray(want[k])), (c, k)

@@ -93,7 +93,8 @@ class Pipeline:
         self.thr = float(detection_treshold)
         self.plate_diameter = plate_diameter
         self.interpreter = Interpreter(model_path, device=device, max_batch=self.n)
-        self.tracker = MultiClipTracker(self.n, int(max_frames) * rows_per_frame, max_age=MAX_AGE, asso_func="diou",
+        self.tracker = MultiClipTracker(self.n, int(max_frames) * rows_per_frame + 3 * 25, max_age=MAX_AGE,   # frames 1-3 may emit 25 rows each
+                                        asso_func="diou",
                                         iou_threshold=0.1, device=device)
         self.frame_count = 0
         self._dev = device
