@@ -702,9 +702,9 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
-                                           "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv"};
+                                           "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node"};
 
 struct Step {
   int op;       // index into ops
@@ -718,9 +718,12 @@ struct Step {
   double alg_bytes_per_frame = 0, weight_bytes = 0, macs_per_frame = 0;
   // fused block (F_MBCONV / F_SEPCONV): constituent op indices (-1 = absent) and kernel arguments
   int e_op = -1, d_op = -1, p_op = -1, a_op = -1;
+  int sum_op = -1;          // F_NODE: the n-ary ADD feeding the depthwise
+  int src_tensor[3] = {-1, -1, -1};
   FusedArgs fa;
   int nbp = 0, lds_bytes = 0;
   int variant = -1;  // kernel variant chosen by the autotuner (-1 = heuristic default)
+  double tuned_ms = 0;
 };
 
 // A group of consecutive graph ops with alternative realisations (all bit-identical); the planner keeps
@@ -811,7 +814,9 @@ static void choose_tile(int OH, int OW, int KK, int S, bool expand, int* TXo, in
   }
 }
 
-static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step* out) {
+struct NodeSrc { int n; int tensor[3]; int mode[3]; int rs_op[3]; };
+
+static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step* out, int sum_op = -1, const NodeSrc* ns = nullptr) {
   const OpRec& dop = m->ops[d_op];
   const OpRec& pop = m->ops[p_op];
   const bool expand = e_op >= 0;
@@ -822,7 +827,8 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   const TensorRec& tout = m->tensors[pop.output];
   const int Ce = tdin.c, Cp = (Ce + 63) / 64 * 64, kk = dop.k * dop.k;
   Step s;
-  s.family = expand ? F_MBCONV : F_SEPCONV;
+  s.family = expand ? F_MBCONV : (sum_op >= 0 ? F_NODE : F_SEPCONV);
+  s.sum_op = sum_op;
   s.op = a_op >= 0 ? a_op : p_op;  // the op whose output this step writes
   s.e_op = e_op; s.d_op = d_op; s.p_op = p_op; s.a_op = a_op;
   FusedArgs& a = s.fa;
@@ -884,12 +890,26 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     a.has_res = 1; a.ka = aop.in_mult[0]; a.kb = aop.in_mult[1];
     a.zr = tr.zero_point; a.lor = aop.act_min; a.hir = aop.act_max;
   }
+  if (sum_op >= 0) {
+    const OpRec& sop = m->ops[sum_op];
+    a.n_src = ns->n;
+    for (int j = 0; j < ns->n; j++) {
+      const TensorRec& ts = m->tensors[ns->tensor[j]];
+      s.src_tensor[j] = ns->tensor[j];
+      a.sh[j] = ts.h; a.sw[j] = ts.w; a.smode[j] = ns->mode[j];
+      a.sz[j] = ts.zero_point; a.sk[j] = sop.in_mult[j];
+      if (ns->mode[j] == 2) { a.spt[j] = m->ops[ns->rs_op[j]].pad_t; a.spl[j] = m->ops[ns->rs_op[j]].pad_l; }
+    }
+    a.sum_lo = sop.act_min; a.sum_hi = sop.act_max;
+  }
   s.nbp = ps.NB <= 3 ? ps.NB : 5;
   const int TXp = (a.TX + 3) & ~3;
   const int NPh = ((TXp - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
   s.lds_bytes = ((NPh * a.T0S + 15) & ~15) + (expand ? NPh * FB_EST : 0) + 64 * FB_DST;
   // accounting = compulsory traffic of the constituent graph ops
-  for (int oi : {e_op, d_op, p_op, a_op})
+  std::vector<int> parts{e_op, d_op, p_op, a_op, sum_op};
+  if (ns) for (int j = 0; j < ns->n; j++) parts.push_back(ns->rs_op[j]);
+  for (int oi : parts)
     if (oi >= 0) {
       s.alg_bytes_per_frame += m->op_steps[oi].alg_bytes_per_frame;
       s.weight_bytes += m->op_steps[oi].weight_bytes;
@@ -914,10 +934,72 @@ static int fuse_plan(vbt_model* m) {
     return d.type == OP_DW && dw_ok(d) && p.type == OP_PW && p.inputs[0] == d.output && consumers[d.output] == 1 &&
            m->tensors[d.inputs[0]].c % 8 == 0 && (m->tensors[p.output].c + 63) / 64 <= 5;
   };
+  // BiFPN nodes: ADD(2|3 inputs) -> DW -> PW where some ADD inputs come from a RESIZE / MAXPOOL used only here
+  const bool fuse_node = fuse_sep && !(m->flags & VBT_MODEL_NO_NODE_FUSION);
+  std::vector<int> producer(m->tensors.size(), -1);
+  for (int i = 0; i < no; i++) producer[m->ops[i].output] = i;
+  std::vector<char> absorbed(no, 0);
+  std::vector<NodeSrc> node_of(no);
+  std::vector<char> is_node(no, 0);
+  if (fuse_node)
+    for (int i = 0; i < no; i++) {
+      const OpRec& ad = m->ops[i];
+      if (ad.type != OP_ADD || ad.n_inputs < 2 || ad.n_inputs > 3 || !sep_ok(i + 1) || m->ops[i + 1].inputs[0] != ad.output ||
+          consumers[ad.output] != 1 || m->tensors[ad.output].c % 4 != 0)
+        continue;
+      NodeSrc ns;
+      ns.n = ad.n_inputs;
+      for (int j = 0; j < ad.n_inputs; j++) {
+        int t = ad.inputs[j], pj = producer[t];
+        ns.tensor[j] = t; ns.mode[j] = 0; ns.rs_op[j] = -1;
+        if (pj >= 0 && consumers[t] == 1 && (m->ops[pj].type == OP_RESIZE_NN || (m->ops[pj].type == OP_MAXPOOL && m->ops[pj].k == 3 && m->ops[pj].stride == 2))) {
+          ns.tensor[j] = m->ops[pj].inputs[0];
+          ns.mode[j] = m->ops[pj].type == OP_RESIZE_NN ? 1 : 2;
+          ns.rs_op[j] = pj;
+          absorbed[pj] = 1;
+        }
+      }
+      node_of[i] = ns;
+      is_node[i] = 1;
+    }
   for (int i = 0; i < no;) {
     const OpRec& op = m->ops[i];
     Group g;
     int span = 1;
+    if (absorbed[i]) { i++; continue; }  // emitted with its node
+    if (is_node[i]) {
+      const NodeSrc& ns = node_of[i];
+      Alt unf, a1, a2;
+      for (int j = 0; j < ns.n; j++)
+        if (ns.rs_op[j] >= 0) { unf.steps.push_back(m->op_steps[ns.rs_op[j]]); a1.steps.push_back(m->op_steps[ns.rs_op[j]]); }
+      unf.steps.push_back(m->op_steps[i]);
+      unf.steps.push_back(m->op_steps[i + 1]);
+      unf.steps.push_back(m->op_steps[i + 2]);
+      g.alts.push_back(unf);
+      a1.steps.push_back(m->op_steps[i]);
+      Step s1, s2;
+      int rc = make_fused(m, -1, i + 1, i + 2, -1, &s1);
+      if (rc) return rc;
+      if (s1.lds_bytes <= 64 * 1024) {
+        a1.steps.push_back(s1);
+        a1.hidden.push_back(m->ops[i + 1].output);
+        g.alts.push_back(a1);
+      }
+      rc = make_fused(m, -1, i + 1, i + 2, -1, &s2, i, &ns);
+      if (rc) return rc;
+      if (s2.lds_bytes <= 64 * 1024) {
+        a2.steps.push_back(s2);
+        for (int j = 0; j < ns.n; j++)
+          if (ns.rs_op[j] >= 0) a2.hidden.push_back(m->ops[ns.rs_op[j]].output);
+        a2.hidden.push_back(op.output);
+        a2.hidden.push_back(m->ops[i + 1].output);
+        g.alts.push_back(a2);
+      }
+      g.chosen = (int)g.alts.size() - 1;
+      m->groups.push_back(g);
+      i += 3;
+      continue;
+    }
     bool mb = op.type == OP_PW && i + 2 < no && m->ops[i + 1].inputs[0] == op.output && consumers[op.output] == 1 && sep_ok(i + 1) &&
               m->tensors[op.inputs[0]].c % 8 == 0;
     if (mb && (fuse_mb || fuse_sep)) {
@@ -1160,7 +1242,26 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       int C = to.c;
       unsigned pb = (unsigned)((128 + ti.zero_point) & 255);
       unsigned pad4 = pb | (pb << 8) | (pb << 16) | (pb << 24);
-      if (s.variant == 0) {  // one output row x 4 columns per lane
+      if (s.variant == 100) {  // LDS-tiled, chunk-parallel
+        DwTileArgs a;
+        a.x = x; a.out = out; a.wf = s.wf; a.bias = s.bias; a.mult = s.mult;
+        a.H = ti.h; a.W = ti.w; a.C = C; a.OH = to.h; a.OW = to.w; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+        choose_tile(to.h, to.w, op.k, op.stride, false, &a.TX, &a.TY);
+        a.tiles_x = (to.w + a.TX - 1) / a.TX;
+        a.tiles_y = (to.h + a.TY - 1) / a.TY;
+        a.zx = ti.zero_point;
+        a.rq = e.rq;
+        const int TXp = (a.TX + 3) & ~3;
+        const int NPh = ((TXp - 1) * op.stride + op.k) * ((a.TY - 1) * op.stride + op.k);
+        dim3 grid((unsigned)((long)B * a.tiles_x * a.tiles_y), (unsigned)((C + 63) / 64));
+        const int lds = NPh * 80;
+#define DW_LAUNCH(KK, S) dw_tile_kernel<KK, S><<<grid, 256, lds, st>>>(a)
+        if (op.k == 3 && op.stride == 1) DW_LAUNCH(3, 1);
+        else if (op.k == 3 && op.stride == 2) DW_LAUNCH(3, 2);
+        else if (op.k == 5 && op.stride == 1) DW_LAUNCH(5, 1);
+        else DW_LAUNCH(5, 2);
+#undef DW_LAUNCH
+      } else if (s.variant == 0) {  // one output row x 4 columns per lane
         long total = (long)B * to.h * ((to.w + 3) / 4) * (C / 4);
         dim3 grid((unsigned)((total + 255) / 256));
 #define DW_LAUNCH(KK, S) dw_kernel<KK, S><<<grid, 256, 0, st>>>(x, s.wf, e, out, total, ti.h, ti.w, C, to.h, to.w, op.pad_t, op.pad_l, pad4)
@@ -1215,9 +1316,11 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       break;
     }
     case F_MBCONV:
+    case F_NODE:
     case F_SEPCONV: {
       FusedArgs a = s.fa;
       a.x = s.e_op >= 0 ? m->tptr[m->ops[s.e_op].inputs[0]] : m->tptr[m->ops[s.d_op].inputs[0]];
+      for (int j = 0; j < 3; j++) a.src[j] = s.src_tensor[j] >= 0 ? m->tptr[s.src_tensor[j]] : nullptr;
       a.out = out;
       const OpRec& dop = m->ops[s.d_op];
       dim3 grid((unsigned)((long)B * a.tiles_x * a.tiles_y));
@@ -1305,6 +1408,7 @@ static void autotune(vbt_model* m) {
           cand = {0};
           for (int r : {1, 2, 4, 8, 16})
             if (r <= m->tensors[op.output].h) cand.push_back(r);
+          if (m->tensors[op.output].c % 8 == 0) cand.push_back(100);
         } else if (st.family == F_PW && st.KS <= 8) {
           cand = {0, 1};
         }
@@ -1317,6 +1421,8 @@ static void autotune(vbt_model* m) {
           if (ms < best) { best = ms; bestv = v; }
         }
         st.variant = bestv;
+        st.macs_per_frame = st.macs_per_frame;  // (unchanged)
+        st.tuned_ms = best;
         a.ms += best;
       }
     }
@@ -1330,7 +1436,7 @@ static void autotune(vbt_model* m) {
       fprintf(stderr, "[autotune] op %3d.. out %3dx%3dx%4d :", f.op, to.h, to.w, to.c);
       for (size_t i = 0; i < g.alts.size(); i++) {
         fprintf(stderr, " alt%zu%s %.1fus(", i, (int)i == bi ? "*" : "", g.alts[i].ms * 1e3);
-        for (const Step& st : g.alts[i].steps) fprintf(stderr, "%s:v%d ", kFamilyName[st.family], st.variant);
+        for (const Step& st : g.alts[i].steps) fprintf(stderr, "%s:v%d=%.1f ", kFamilyName[st.family], st.variant, st.tuned_ms * 1e3);
         fprintf(stderr, ")");
       }
       fprintf(stderr, "\n");

@@ -47,6 +47,13 @@ struct FusedArgs {
   int has_res;
   float ka, kb;
   int zr, lor, hir;
+  // BiFPN node: the tile is the n-ary ADD (+ReLU6) of up to three sources, each read through a
+  // resampling map (0 identity, 1 nearest-neighbour up: src = floor(dst*in/out), 2 max-pool 3x3/2 SAME)
+  int n_src;
+  const int8_t* src[3];
+  int sh[3], sw[3], smode[3], spt[3], spl[3], sz[3];
+  float sk[3];
+  int sum_lo, sum_hi;  // clamp of the sum (its zero point is zx)
 };
 
 constexpr int FB_EST = 80;  // E tile bytes per pixel (64 + 16: bank spread, 16-B aligned)
@@ -69,19 +76,82 @@ __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
   unsigned char* E = T0 + ((NPh * a.T0S + 15) & ~15);
   unsigned char* D = E + (EXPAND ? NPh * FB_EST : 0);
 
-  // ---- stage L: input halo tile -> LDS (8-byte granules, coalesced along channels) ----
-  {
+  // ---- stage L: input halo tile -> LDS ----
+  bool summed = false;
+  if constexpr (!EXPAND) summed = a.n_src > 0;
+  if (summed) {
+    // BiFPN node input: resample + n-ary add + clamp, 4 channels per lane-iteration (same float ops as add_kernel)
+    const int nd = a.Cin >> 2;
+    const unsigned zb4 = (unsigned)(a.zx & 255) * 0x01010101u;
+    const int pstep = 256 / nd;                       // pixels advanced per round (planner guarantees nd <= 256)
+    int p = tid / nd;
+    const int cd = tid - p * nd;
+    int hy = p / HWx, hx = p - hy * HWx;
+    const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
+    for (; tid < pstep * nd && p < NPh; p += pstep) {
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      hx += pstep;
+      while (hx >= HWx) { hx -= HWx; hy++; }
+      unsigned v = zb4;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          if (j < a.n_src) {
+            const int8_t* sb = a.src[j] + b * (long)a.sh[j] * a.sw[j] * a.Cin + 4 * cd;
+            unsigned u;
+            if (a.smode[j] == 0) {
+              u = *(const unsigned*)(sb + ((long)iy * a.sw[j] + ix) * a.Cin);
+            } else if (a.smode[j] == 1) {
+              int yy, xx;
+              if (up2[j]) { yy = iy >> 1; xx = ix >> 1; }
+              else { yy = (iy * a.sh[j]) / a.H; xx = (ix * a.sw[j]) / a.W; }
+              u = *(const unsigned*)(sb + ((long)yy * a.sw[j] + xx) * a.Cin);
+            } else {
+              int m0 = -128, m1 = -128, m2 = -128, m3 = -128;
+              for (int ky = 0; ky < 3; ky++) {
+                int yy = iy * 2 + ky - a.spt[j];
+                if (yy < 0 || yy >= a.sh[j]) continue;
+                for (int kx = 0; kx < 3; kx++) {
+                  int xx = ix * 2 + kx - a.spl[j];
+                  if (xx < 0 || xx >= a.sw[j]) continue;
+                  unsigned t = *(const unsigned*)(sb + ((long)yy * a.sw[j] + xx) * a.Cin);
+                  m0 = max(m0, (int)(int8_t)(t & 255u)); m1 = max(m1, (int)(int8_t)((t >> 8) & 255u));
+                  m2 = max(m2, (int)(int8_t)((t >> 16) & 255u)); m3 = max(m3, (int)(int8_t)(t >> 24));
+                }
+              }
+              u = pack4(m0, m1, m2, m3);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              float f = (float)((int)(int8_t)(u >> (8 * e)) - a.sz[j]);
+              rr[e] = j == 0 ? f * a.sk[0] : __builtin_fmaf(f, a.sk[j], rr[e]);
+            }
+          }
+        }
+        int q[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) q[e] = min(max((int)__builtin_rintf(rr[e]) + a.zx, a.sum_lo), a.sum_hi);
+        v = pack4(q[0], q[1], q[2], q[3]);
+      }
+      *(unsigned*)(T0 + p * a.T0S + 4 * cd) = v;
+    }
+  } else {
+    // plain tensor: 8-byte granules, coalesced along channels; (hy,hx) advance incrementally (no divisions in the loop)
     const int ng = a.Cin >> 3;
-    const int total = NPh * ng;
     const unsigned long long zb = (unsigned long long)(a.zx & 255) * 0x0101010101010101ull;
     const int8_t* xb = a.x + b * (long)a.H * a.W * a.Cin;
-    for (int gi = tid; gi < total; gi += 256) {
-      int p = gi / ng, sg = gi - p * ng;
-      int hy = p / HWx, hx = p - hy * HWx;
-      int iy = iy0 + hy, ix = ix0 + hx;
+    const int pstep = 256 / ng;
+    int p = tid / ng;
+    const int sg = tid - p * ng;
+    int hy = p / HWx, hx = p - hy * HWx;
+    for (; tid < pstep * ng && p < NPh; p += pstep) {
+      const int iy = iy0 + hy, ix = ix0 + hx;
       unsigned long long v = zb;
       if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const unsigned long long*)(xb + ((long)iy * a.W + ix) * a.Cin + 8 * sg);
       *(unsigned long long*)(T0 + p * a.T0S + 8 * sg) = v;
+      hx += pstep;
+      while (hx >= HWx) { hx -= HWx; hy++; }
     }
   }
   // which of this wave's halo pixel groups hold out-of-image pixels (expand epilogue), bit i <-> pg = wave + 4i
@@ -243,6 +313,114 @@ __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; j++)
             if (c0 + 4 * t + j < a.Cout) o[4 * t + j] = (int8_t)(d[t] >> (8 * j));
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// LDS-tiled depthwise conv (stand-alone): the depthwise stage above with a chunk-parallel grid.
+// grid.x = image tiles, grid.y = 64-channel chunks; the halo tile of the chunk is staged in LDS with
+// 8-byte coalesced loads, every lane then computes 4 channels x 4 output columns from LDS and stores
+// its dwords straight to HBM.  Used where the column walker is a serial latency chain (small maps,
+// many channels).
+// ------------------------------------------------------------------------------------------
+struct DwTileArgs {
+  const int8_t* x;
+  int8_t* out;
+  const float* wf;   // [k*k][C]
+  const int* bias;   // folded
+  const float* mult;
+  int H, W, C, OH, OW, pad_t, pad_l, TX, TY, tiles_x, tiles_y, zx;
+  Rq rq;
+};
+
+template <int KK, int S>
+__global__ __launch_bounds__(256) void dw_tile_kernel(DwTileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dt_smem[];
+  constexpr int TS = 80;  // bytes per halo pixel (64 channels + pad)
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int tx = tile % a.tiles_x;
+  tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y;
+  const long b = tile / a.tiles_y;
+  const int c0 = blockIdx.y * 64;
+  const int cvalid = min(64, a.C - c0);  // channels of this chunk (multiple of 4)
+  const int oy0 = ty * a.TY, ox0 = tx * a.TX;
+  const int TXp = (a.TX + 3) & ~3;
+  const int HWx = (TXp - 1) * S + KK, HWy = (a.TY - 1) * S + KK, NPh = HWx * HWy;
+  const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
+  {
+    const int ng = (cvalid + 7) >> 3;  // 8-byte granules per pixel (C % 8 == 0 is required by the planner)
+    const unsigned long long zb = (unsigned long long)(a.zx & 255) * 0x0101010101010101ull;
+    const int8_t* xb = a.x + b * (long)a.H * a.W * a.C + c0;
+    const int pstep = 256 / ng;
+    int p = tid / ng;
+    const int sg = tid - p * ng;
+    int hy = p / HWx, hx = p - hy * HWx;
+    for (; tid < pstep * ng && p < NPh; p += pstep) {
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      unsigned long long v = zb;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const unsigned long long*)(xb + ((long)iy * a.W + ix) * a.C + 8 * sg);
+      *(unsigned long long*)(dt_smem + p * TS + 8 * sg) = v;
+      hx += pstep;
+      while (hx >= HWx) { hx -= HWx; hy++; }
+    }
+  }
+  const int cq = tid & 15, strip = tid >> 4;
+  const int nsx = TXp >> 2;
+  const int sy = strip / nsx, sx = (strip - sy * nsx) * 4;
+  const bool active = sy < a.TY && 4 * cq < cvalid;
+  // parameters are fetched while the tile loads are in flight
+  float4 wr[KK][KK];
+  int4 bq = make_int4(0, 0, 0, 0);
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+#pragma unroll
+    for (int ky = 0; ky < KK; ky++)
+#pragma unroll
+      for (int kx = 0; kx < KK; kx++) wr[ky][kx] = *(const float4*)(a.wf + (long)(ky * KK + kx) * a.C + c0 + 4 * cq);
+    bq = *(const int4*)(a.bias + c0 + 4 * cq);
+    mu = *(const float4*)(a.mult + c0 + 4 * cq);
+  }
+  __syncthreads();
+  if (!active) return;
+  constexpr int IW = 3 * S + KK;
+  float dacc[4][4];
+#pragma unroll
+  for (int o = 0; o < 4; o++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) dacc[o][j] = 0.0f;
+#pragma unroll
+  for (int ky = 0; ky < KK; ky++) {
+    const unsigned char* rowp = dt_smem + ((sy * S + ky) * HWx + sx * S) * TS + 4 * cq;
+#pragma unroll
+    for (int j = 0; j < IW; j++) {
+      unsigned u = *(const unsigned*)(rowp + j * TS) ^ 0x80808080u;
+      float f0 = (float)(u & 255u), f1 = (float)((u >> 8) & 255u), f2 = (float)((u >> 16) & 255u), f3 = (float)(u >> 24);
+#pragma unroll
+      for (int kx = 0; kx < KK; kx++) {
+        if ((j - kx) >= 0 && (j - kx) % S == 0 && (j - kx) / S < 4) {
+          const int o = (j - kx) / S;
+          dacc[o][0] = __builtin_fmaf(f0, wr[ky][kx].x, dacc[o][0]);
+          dacc[o][1] = __builtin_fmaf(f1, wr[ky][kx].y, dacc[o][1]);
+          dacc[o][2] = __builtin_fmaf(f2, wr[ky][kx].z, dacc[o][2]);
+          dacc[o][3] = __builtin_fmaf(f3, wr[ky][kx].w, dacc[o][3]);
+        }
+      }
+    }
+  }
+  const int oy = oy0 + sy;
+  if (oy < a.OH) {
+    int8_t* orow = a.out + ((b * a.OH + oy) * (long)a.OW) * a.C + c0 + 4 * cq;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      const int ox = ox0 + sx + o;
+      if (sx + o < a.TX && ox < a.OW) {
+        const v4i ai = {(int)dacc[o][0], (int)dacc[o][1], (int)dacc[o][2], (int)dacc[o][3]};
+        *(unsigned*)(orow + (long)ox * a.C) = rq_pack_i(ai, bq, mu, a.rq);
       }
     }
   }
