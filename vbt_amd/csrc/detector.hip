@@ -763,6 +763,9 @@ struct vbt_model {
   std::vector<Step> op_steps;   // one per graph op (weights live here)
   std::vector<char> materialized;  // per tensor: written to HBM by the execution list
   int flags = 0;
+  int n_sub = 1;                         // sub-batches run concurrently on side streams
+  hipStream_t sub_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<void*> owned;  // device allocations to free
   int last_B = 0;
 };
@@ -869,6 +872,33 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     int rc;
     if ((rc = upload(m, wf, &dwf)) || (rc = upload(m, bias, &dbias)) || (rc = upload(m, mult, &dmult))) return rc;
     a.wd = dwf; a.bd = dbias; a.md = dmult;
+    // matrix-pipe form: [chunk][cg][m][lane][8]: lane (i = lane&15 -> channel 64*chunk + 16*cg + i, g): k = 8g + j ->
+    // tap 2m + (g>>1), channel-in-group 8(g&1) + j; non-zero only on the diagonal
+    const int KT = (kk + 1) / 2;
+    std::vector<long> wdm((size_t)(Cp / 64) * 4 * KT * 64, 0);
+    std::vector<int> biasm(Cp, 0);
+    int8_t* wb = (int8_t*)wdm.data();
+    for (int ch = 0; ch < Cp / 64; ch++)
+      for (int cg = 0; cg < 4; cg++)
+        for (int mi = 0; mi < KT; mi++)
+          for (int lane = 0; lane < 64; lane++) {
+            int i = lane & 15, g = lane >> 4;
+            int c = 64 * ch + 16 * cg + i;
+            int tap = 2 * mi + (g >> 1);
+            for (int j = 0; j < 8; j++) {
+              int cp = 8 * (g & 1) + j;
+              int8_t v = (tap < kk && cp == i && c < Ce) ? w[(size_t)tap * Ce + c] : 0;
+              wb[((((size_t)(ch * 4 + cg) * KT + mi) * 64 + lane) * 8) + j] = v;
+            }
+          }
+    for (int c = 0; c < Ce; c++) {
+      long sw = 0;
+      for (int t = 0; t < kk; t++) sw += w[(size_t)t * Ce + c];
+      biasm[c] = (int)((long)bq[c] - (long)tdin.zero_point * sw);
+    }
+    long* dwdm; int* dbm;
+    if ((rc = upload(m, wdm, &dwdm)) || (rc = upload(m, biasm, &dbm))) return rc;
+    a.wdm = dwdm; a.bdm = dbm;
     a.zd = tdout.zero_point; a.lod = dop.act_min; a.hid = dop.act_max;
     a.rqd = make_rq(a.zd, a.lod, a.hid);
   }
@@ -1182,11 +1212,18 @@ static void launch_pw_a(int MS, dim3 grid, hipStream_t st, const int8_t* x, cons
   else pw_a_kernel<KS, 1><<<grid, 256, 0, st>>>(x, wp, e, out, M, K, N, NB, nb_per_y);
 }
 
+// Launches one plan step for frames [boff, boff + B) of the batch (every tensor is batch-major).
 static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const uint8_t* frames, float* boxes, float* scores,
-                       float* classes, int* counts) {
+                       float* classes, int* counts, int boff = 0) {
   const OpRec& op = m->ops[s.op];
   const TensorRec& to = m->tensors[op.output];
-  int8_t* out = m->tptr[op.output];
+  auto TP = [&](int t) { return m->tptr[t] + (size_t)boff * m->telems[t]; };
+  frames += (size_t)boff * m->hdr.image_size * m->hdr.image_size * 3;
+  boxes += (size_t)boff * m->hdr.max_detections * 4;
+  scores += (size_t)boff * m->hdr.max_detections;
+  classes += (size_t)boff * m->hdr.max_detections;
+  counts += boff;
+  int8_t* out = TP(op.output);
   Epi e{s.bias, s.mult, to.zero_point, op.act_min, op.act_max, make_rq(to.zero_point, op.act_min, op.act_max)};
   switch (s.family) {
     case F_STEM: {
@@ -1198,7 +1235,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
     }
     case F_PW: {
       const TensorRec& ti = m->tensors[op.inputs[0]];
-      const int8_t* x = m->tptr[op.inputs[0]];
+      const int8_t* x = TP(op.inputs[0]);
       long M = (long)B * to.h * to.w;
       int K = ti.c, N = to.c;
       if (s.KS <= 8) {
@@ -1238,7 +1275,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
     }
     case F_DW: {
       const TensorRec& ti = m->tensors[op.inputs[0]];
-      const int8_t* x = m->tptr[op.inputs[0]];
+      const int8_t* x = TP(op.inputs[0]);
       int C = to.c;
       unsigned pb = (unsigned)((128 + ti.zero_point) & 255);
       unsigned pad4 = pb | (pb << 8) | (pb << 16) | (pb << 24);
@@ -1292,7 +1329,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       a.n_in = op.n_inputs;
       for (int i = 0; i < 3; i++) {
         int ii = i < op.n_inputs ? i : 0;
-        a.in[i] = m->tptr[op.inputs[ii]];
+        a.in[i] = TP(op.inputs[ii]);
         a.z[i] = m->tensors[op.inputs[ii]].zero_point;
         a.k[i] = op.in_mult[ii];
       }
@@ -1304,14 +1341,14 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
     case F_MAXPOOL: {
       const TensorRec& ti = m->tensors[op.inputs[0]];
       long total = (long)B * to.h * to.w * (to.c / 4);
-      maxpool_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(m->tptr[op.inputs[0]], out, total, ti.h, ti.w, ti.c,
+      maxpool_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(TP(op.inputs[0]), out, total, ti.h, ti.w, ti.c,
                                                                              to.h, to.w, op.pad_t, op.pad_l);
       break;
     }
     case F_RESIZE: {
       const TensorRec& ti = m->tensors[op.inputs[0]];
       long total = (long)B * to.h * to.w * (to.c / 4);
-      resize_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(m->tptr[op.inputs[0]], out, total, ti.h, ti.w, ti.c,
+      resize_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(TP(op.inputs[0]), out, total, ti.h, ti.w, ti.c,
                                                                             to.h, to.w);
       break;
     }
@@ -1319,16 +1356,19 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
     case F_NODE:
     case F_SEPCONV: {
       FusedArgs a = s.fa;
-      a.x = s.e_op >= 0 ? m->tptr[m->ops[s.e_op].inputs[0]] : m->tptr[m->ops[s.d_op].inputs[0]];
-      for (int j = 0; j < 3; j++) a.src[j] = s.src_tensor[j] >= 0 ? m->tptr[s.src_tensor[j]] : nullptr;
+      a.x = s.e_op >= 0 ? TP(m->ops[s.e_op].inputs[0]) : TP(m->ops[s.d_op].inputs[0]);
+      for (int j = 0; j < 3; j++) a.src[j] = s.src_tensor[j] >= 0 ? TP(s.src_tensor[j]) : nullptr;
       a.out = out;
       const OpRec& dop = m->ops[s.d_op];
       dim3 grid((unsigned)((long)B * a.tiles_x * a.tiles_y));
       const bool ex = s.family == F_MBCONV;
+      const bool mdw = s.variant != 0;  // variant 0: depthwise on the VALU; default / 1: on the matrix pipe
 #define FB_LAUNCH(KK, S, NBP)                                                                              \
   do {                                                                                                     \
-    if (ex) fused_block_kernel<KK, S, NBP, true><<<grid, 256, s.lds_bytes, st>>>(a);                        \
-    else fused_block_kernel<KK, S, NBP, false><<<grid, 256, s.lds_bytes, st>>>(a);                          \
+    if (ex && mdw) fused_block_kernel<KK, S, NBP, true, true><<<grid, 256, s.lds_bytes, st>>>(a);           \
+    else if (ex) fused_block_kernel<KK, S, NBP, true, false><<<grid, 256, s.lds_bytes, st>>>(a);            \
+    else if (mdw) fused_block_kernel<KK, S, NBP, false, true><<<grid, 256, s.lds_bytes, st>>>(a);           \
+    else fused_block_kernel<KK, S, NBP, false, false><<<grid, 256, s.lds_bytes, st>>>(a);                   \
   } while (0)
 #define FB_NBP(KK, S)                                      \
   do {                                                     \
@@ -1352,8 +1392,8 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       int base = 0;
       for (int l = 0; l < 5; l++) {
         const TensorRec& tc = m->tensors[op.inputs[l]];
-        p.cls[l] = m->tptr[op.inputs[l]];
-        p.box[l] = m->tptr[op.inputs[5 + l]];
+        p.cls[l] = TP(op.inputs[l]);
+        p.box[l] = TP(op.inputs[5 + l]);
         p.base[l] = base;
         base += tc.h * tc.w * tc.c;
       }
@@ -1392,7 +1432,7 @@ static double time_step(vbt_model* m, const Step& s, int B, int reps) {
 
 // Plan-time autotuning: every alternative computes bit-identical tensors, so only speed is at stake.
 static void autotune(vbt_model* m) {
-  const int B = m->max_batch, reps = 4;
+  const int B = (m->max_batch + m->n_sub - 1) / m->n_sub, reps = 4;  // the batch one stream actually sees
   for (Group& g : m->groups) {
     bool single = g.alts.size() == 1 && g.alts[0].steps.size() == 1;
     if (single) {
@@ -1410,6 +1450,8 @@ static void autotune(vbt_model* m) {
             if (r <= m->tensors[op.output].h) cand.push_back(r);
           if (m->tensors[op.output].c % 8 == 0) cand.push_back(100);
         } else if (st.family == F_PW && st.KS <= 8) {
+          cand = {0, 1};
+        } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
           cand = {0, 1};
         }
         double best = 1e30;
@@ -1447,14 +1489,34 @@ static void autotune(vbt_model* m) {
 
 static int enqueue_forward(vbt_model* m, const uint8_t* frames_dev, int B, hipStream_t st, float* boxes, float* scores,
                            float* classes, int* counts, hipEvent_t* evs) {
-  int i = 0;
-  for (const Step& s : m->steps) {
+  const int nsub = (!evs && m->n_sub > 1 && B >= 2 * m->n_sub) ? m->n_sub : 1;
+  if (nsub == 1) {
+    int i = 0;
+    for (const Step& s : m->steps) {
+      if (evs) (void)hipEventRecord(evs[i], st);
+      int rc = launch_step(m, s, B, st, frames_dev, boxes, scores, classes, counts);
+      if (rc) return rc;
+      i++;
+    }
     if (evs) (void)hipEventRecord(evs[i], st);
-    int rc = launch_step(m, s, B, st, frames_dev, boxes, scores, classes, counts);
-    if (rc) return rc;
-    i++;
+  } else {
+    // Independent sub-batches on side streams: the many small, latency-bound kernels of one sub-batch overlap
+    // with the other's.  Fork from / join into the caller's stream with events.
+    (void)hipEventRecord(m->ev_fork, st);
+    const int per = (B + nsub - 1) / nsub;
+    for (int k = 0; k < nsub; k++) {
+      const int b0 = k * per, bk = std::min(per, B - b0);
+      if (bk <= 0) break;
+      hipStream_t ss = m->sub_streams[k];
+      (void)hipStreamWaitEvent(ss, m->ev_fork, 0);
+      for (const Step& s : m->steps) {
+        int rc = launch_step(m, s, bk, ss, frames_dev, boxes, scores, classes, counts, b0);
+        if (rc) return rc;
+      }
+      (void)hipEventRecord(m->ev_join[k], ss);
+      (void)hipStreamWaitEvent(st, m->ev_join[k], 0);
+    }
   }
-  if (evs) (void)hipEventRecord(evs[i], st);
   VBT_HIP_CHECK(hipGetLastError());
   m->last_B = B;
   return VBT_OK;
@@ -1547,6 +1609,20 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
       std::vector<float> lut((const float*)(m->blob.data() + op.aux2_off), (const float*)(m->blob.data() + op.aux2_off) + 768);
       if ((rc = upload(m, an, &m->d_anchors)) || (rc = upload(m, lut, &m->d_luts))) return fail(rc);
     }
+  {
+    const char* ns = getenv("VBT_SUBSTREAMS");
+    int want = ns ? atoi(ns) : 1;  // side streams measured no gain on MI355X at B = 64 (the GPU is busy, not starved)
+    if (m->flags & VBT_MODEL_SINGLE_STREAM) want = 1;
+    m->n_sub = std::max(1, std::min(want, 4));
+    if (max_batch < 2 * m->n_sub) m->n_sub = 1;
+    if (m->n_sub > 1) {
+      bool ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+      for (int k = 0; k < m->n_sub && ok; k++)
+        ok = hipStreamCreateWithFlags(&m->sub_streams[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&m->ev_join[k], hipEventDisableTiming) == hipSuccess;
+      if (!ok) { set_error("cannot create side streams"); return fail(VBT_ERR_HIP); }
+    }
+  }
   if (!(m->flags & VBT_MODEL_NO_AUTOTUNE)) autotune(m);
   finalize_plan(m);
   *out = m;
@@ -1555,6 +1631,11 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
 
 void vbt_model_destroy(vbt_model* m) {
   if (!m) return;
+  for (int k = 0; k < 4; k++) {
+    if (m->sub_streams[k]) (void)hipStreamDestroy(m->sub_streams[k]);
+    if (m->ev_join[k]) (void)hipEventDestroy(m->ev_join[k]);
+  }
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
   for (void* p : m->owned) (void)hipFree(p);
   (void)hipFree(m->arena); (void)hipFree(m->frames_stage); (void)hipFree(m->out_boxes);
   (void)hipFree(m->out_scores); (void)hipFree(m->out_classes); (void)hipFree(m->out_counts);

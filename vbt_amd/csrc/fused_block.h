@@ -37,6 +37,10 @@ struct FusedArgs {
   const float* md;
   int zd, lod, hid;
   Rq rqd;
+  // depthwise on the matrix pipe (MDW): diagonal-embedded weights [chunk][cg][m][lane] x 8 B and the bias
+  // folded for raw int8 inputs (bias - z_x * sum(w))
+  const long* wdm;
+  const int* bdm;
   // project
   const long* wp;   // packed, K = Ce_pad
   const int* bp;
@@ -59,7 +63,7 @@ struct FusedArgs {
 constexpr int FB_EST = 80;  // E tile bytes per pixel (64 + 16: bank spread, 16-B aligned)
 constexpr int FB_DST = 72;  // D tile bytes per pixel
 
-template <int KK, int S, int NBP, bool EXPAND>
+template <int KK, int S, int NBP, bool EXPAND, bool MDW>
 __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -177,6 +181,16 @@ __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
   const int nsx = TXp >> 2;
   const int sy = strip / nsx, sx = (strip - sy * nsx) * 4;
   const bool dw_active = sy < a.TY;
+  // MDW: lane (r = pixel of a 16-slot group, g) -> halo offset of the slot's window origin, per slot group
+  int hbase[4] = {0, 0, 0, 0};
+  if constexpr (MDW) {
+#pragma unroll
+    for (int pg = 0; pg < 4; pg++) {
+      int slot = pg * 16 + r;
+      int py_ = min(slot / TXp, a.TY - 1), px_ = slot - (slot / TXp) * TXp;
+      hbase[pg] = (py_ * S) * HWx + px_ * S;
+    }
+  }
   __syncthreads();
 
   for (int c = 0; c < a.nchunks; c++) {
@@ -213,7 +227,37 @@ __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
       __syncthreads();
     }
     // ---- stage D: depthwise on chunk c ----
-    if (dw_active) {
+    if constexpr (MDW) {
+      // Matrix-pipe depthwise: out[c][p] = sum_t W'[c][(t,c')] * X[(t,c')][p] with W' = w[t][c] * delta(c,c').
+      // One 16x16x32 MFMA covers 2 taps x 16 channels; wave w owns channel group w of the chunk, the B operand
+      // (8 consecutive channels of pixel p + tap) is a single ds_read_b64 from the NHWC tile.  Exact int32.
+      constexpr int KT = (KK * KK + 1) / 2;
+      const unsigned char* Ein = EXPAND ? E : T0 + 64 * c;
+      const int est = EXPAND ? FB_EST : a.T0S;
+      const long* wm = a.wdm + ((long)(c * 4 + wave) * KT) * 64 + lane;
+      long wreg[KT];
+#pragma unroll
+      for (int mi = 0; mi < KT; mi++) wreg[mi] = wm[mi * 64];
+      const int4 bqm = *(const int4*)(a.bdm + c * 64 + 16 * wave + 4 * g);
+      const float4 mum = *(const float4*)(a.md + c * 64 + 16 * wave + 4 * g);
+      const unsigned char* lane_base = Ein + 16 * wave + 8 * (g & 1);
+      const int hi_half = g >> 1;
+#pragma unroll
+      for (int pg = 0; pg < 4; pg++) {
+        v4i dq = {0, 0, 0, 0};
+        const unsigned char* pb = lane_base + hbase[pg] * est;
+#pragma unroll
+        for (int mi = 0; mi < KT; mi++) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int ta = 2 * mi, tb = (2 * mi + 1 < KK * KK) ? 2 * mi + 1 : 2 * mi;  // odd tap count: the pad tap has zero weights
+          const int offa = ((ta / KK) * HWx + (ta % KK)) * est, offb = ((tb / KK) * HWx + (tb % KK)) * est;
+          long bv = *(const long*)(pb + (hi_half ? offb : offa));
+          dq = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bv, dq, 0, 0, 0);
+        }
+        *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_i(dq, bqm, mum, a.rqd);
+      }
+    } else if (dw_active) {
       const unsigned char* Ein = EXPAND ? E + 4 * cq : T0 + 64 * c + 4 * cq;
       const int est = EXPAND ? FB_EST : a.T0S;
       constexpr int IW = 3 * S + KK;
