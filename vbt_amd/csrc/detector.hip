@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <tuple>
 
 #include "common.h"
 
@@ -702,9 +703,9 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
-                                           "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node"};
+                                           "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node", "fused_heads_multi"};
 
 struct Step {
   int op;       // index into ops
@@ -724,6 +725,9 @@ struct Step {
   int nbp = 0, lds_bytes = 0;
   int variant = -1;  // kernel variant chosen by the autotuner (-1 = heuristic default)
   double tuned_ms = 0;
+  // F_MULTI: independent fused problems launched as one grid
+  std::vector<Step> members;
+  FusedArgs* d_multi = nullptr;
 };
 
 // A group of consecutive graph ops with alternative realisations (all bit-identical); the planner keeps
@@ -766,6 +770,16 @@ struct vbt_model {
   int n_sub = 1;                         // sub-batches run concurrently on side streams
   hipStream_t sub_streams[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // hipGraph replay of the forward for launch-bound (small) batches: one executable graph per (B, buffers)
+  struct GraphKey {
+    const void* frames; void* boxes; void* scores; void* classes; void* counts; int B;
+    bool operator<(const GraphKey& o) const {
+      return std::tie(frames, boxes, scores, classes, counts, B) < std::tie(o.frames, o.boxes, o.scores, o.classes, o.counts, o.B);
+    }
+  };
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  hipStream_t cap_stream = nullptr;
+  int graph_max_batch = 0;  // 0 = graphs off
   std::vector<void*> owned;  // device allocations to free
   int last_B = 0;
 };
@@ -949,6 +963,102 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   return VBT_OK;
 }
 
+// The box / class heads run the same SeparableConv chain on 5 pyramid levels (x 2 heads): layer j of every
+// chain is independent of layer j of the others, so all of them go out as ONE grid (fused_block_multi_kernel).
+static int batch_heads(vbt_model* m) {
+  struct Info { int gi, chain, depth; };
+  std::vector<Info> heads;
+  std::map<int, std::pair<int, int>> by_tensor;  // output tensor -> (chain, depth)
+  int nchains = 0, first = -1;
+  for (int gi = 0; gi < (int)m->groups.size(); gi++) {
+    const Group& g = m->groups[gi];
+    const Alt& fa = g.alts.back();
+    if (fa.steps.size() != 1 || fa.steps[0].family != F_SEPCONV) continue;
+    const Step& st = fa.steps[0];
+    if (m->ops[st.d_op].level < 0) continue;
+    int tin = m->ops[st.d_op].inputs[0], tout = m->ops[st.p_op].output;
+    auto it = by_tensor.find(tin);
+    int chain = it == by_tensor.end() ? nchains++ : it->second.first;
+    int depth = it == by_tensor.end() ? 0 : it->second.second + 1;
+    by_tensor[tout] = {chain, depth};
+    heads.push_back({gi, chain, depth});
+    if (first < 0) first = gi;
+  }
+  if (heads.size() < 2) return VBT_OK;
+  int maxd = 0;
+  for (auto& h : heads) maxd = std::max(maxd, h.depth);
+  // Depth d may only be merged if every deeper layer is merged too: an unmerged successor sits right behind its
+  // own predecessor in list order, i.e. ahead of the merged launch that would produce its input.
+  auto members_of = [&](int d) {
+    std::vector<int> mem;
+    for (auto& h : heads)
+      if (h.depth == d) mem.push_back(h.gi);
+    return mem;
+  };
+  auto mergeable = [&](const std::vector<int>& mem) {
+    if (mem.size() < 2 || mem.size() > 12) return false;
+    const Step& s0 = m->groups[mem[0]].alts.back().steps[0];
+    if (!(s0.nbp == 1 && m->ops[s0.d_op].k == 3 && m->ops[s0.d_op].stride == 1)) return false;  // the instantiation built below
+    for (int gi : mem) {
+      const Step& st = m->groups[gi].alts.back().steps[0];
+      if (st.nbp != s0.nbp || m->ops[st.d_op].k != 3 || m->ops[st.d_op].stride != 1) return false;
+    }
+    return true;
+  };
+  int d0 = maxd + 1;
+  while (d0 > 0 && mergeable(members_of(d0 - 1))) d0--;
+  if (d0 > maxd) return VBT_OK;
+  std::map<int, Group> at;  // position (index of the last member) -> merged group
+  std::vector<char> consumed(m->groups.size(), 0);
+  for (int d = d0; d <= maxd; d++) {
+    std::vector<int> mem = members_of(d);
+    const Step& s0 = m->groups[mem[0]].alts.back().steps[0];
+    Group g;
+    Alt unf, each, multi;
+    Step ms;
+    ms.family = F_MULTI;
+    ms.op = s0.op;
+    ms.d_op = s0.d_op;
+    ms.nbp = s0.nbp;
+    std::vector<FusedArgs> hargs;
+    int last = 0;
+    for (int gi : mem) {
+      const Group& src = m->groups[gi];
+      for (const Step& st : src.alts[0].steps) unf.steps.push_back(st);
+      const Step& fs = src.alts.back().steps[0];
+      each.steps.push_back(fs);
+      for (int t : src.alts.back().hidden) { each.hidden.push_back(t); multi.hidden.push_back(t); }
+      ms.members.push_back(fs);
+      ms.lds_bytes = std::max(ms.lds_bytes, fs.lds_bytes);
+      ms.alg_bytes_per_frame += fs.alg_bytes_per_frame;
+      ms.weight_bytes += fs.weight_bytes;
+      ms.macs_per_frame += fs.macs_per_frame;
+      FusedArgs a = fs.fa;
+      a.x = m->tptr[m->ops[fs.d_op].inputs[0]];
+      a.out = m->tptr[m->ops[fs.op].output];
+      hargs.push_back(a);
+      consumed[gi] = 1;
+      last = std::max(last, gi);
+    }
+    int rc = upload(m, hargs, &ms.d_multi);
+    if (rc) return rc;
+    multi.steps.push_back(ms);
+    g.alts.push_back(unf);
+    g.alts.push_back(each);
+    g.alts.push_back(multi);
+    g.chosen = 2;
+    at[last] = g;
+  }
+  std::vector<Group> out;
+  for (int gi = 0; gi < (int)m->groups.size(); gi++) {
+    if (!consumed[gi]) out.push_back(m->groups[gi]);
+    auto it = at.find(gi);
+    if (it != at.end()) out.push_back(it->second);
+  }
+  m->groups.swap(out);
+  return VBT_OK;
+}
+
 static int fuse_plan(vbt_model* m) {
   const int no = (int)m->ops.size();
   std::vector<int> consumers(m->tensors.size(), 0);
@@ -1095,6 +1205,10 @@ static int fuse_plan(vbt_model* m) {
     g.chosen = (int)g.alts.size() - 1;  // without autotuning: the most fused alternative
     m->groups.push_back(g);
     i += span;
+  }
+  if (fuse_sep && !(m->flags & VBT_MODEL_NO_HEAD_BATCHING)) {
+    int rc = batch_heads(m);
+    if (rc) return rc;
   }
   return VBT_OK;
 }
@@ -1352,6 +1466,37 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
                                                                             to.h, to.w);
       break;
     }
+    case F_MULTI: {
+      if (boff != 0) {  // side-stream sub-batches: pointers differ, launch the members one by one
+        for (const Step& ms : s.members) {
+          Step t = ms;
+          t.variant = s.variant;
+          int rc = launch_step(m, t, B, st, frames - (size_t)boff * m->hdr.image_size * m->hdr.image_size * 3, boxes - (size_t)boff * m->hdr.max_detections * 4,
+                               scores - (size_t)boff * m->hdr.max_detections, classes - (size_t)boff * m->hdr.max_detections, counts - boff, boff);
+          if (rc) return rc;
+        }
+        break;
+      }
+      MultiTiles mt;
+      mt.n = (int)s.members.size();
+      int acc = 0;
+      for (int i = 0; i < mt.n; i++) {
+        mt.start[i] = acc;
+        acc += B * s.members[i].fa.tiles_x * s.members[i].fa.tiles_y;
+      }
+      mt.start[mt.n] = acc;
+      const OpRec& dop = m->ops[s.d_op];
+      dim3 grid((unsigned)acc);
+      const bool mdw = s.variant != 0;
+      if (dop.k == 3 && dop.stride == 1 && s.nbp == 1) {
+        if (mdw) fused_block_multi_kernel<3, 1, 1, false, true><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
+        else fused_block_multi_kernel<3, 1, 1, false, false><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
+      } else {
+        set_error("fused_heads_multi: unsupported instantiation (k=%d s=%d nbp=%d)", dop.k, dop.stride, s.nbp);
+        return VBT_ERR_ARG;
+      }
+      break;
+    }
     case F_MBCONV:
     case F_NODE:
     case F_SEPCONV: {
@@ -1451,7 +1596,7 @@ static void autotune(vbt_model* m) {
           if (m->tensors[op.output].c % 8 == 0) cand.push_back(100);
         } else if (st.family == F_PW && st.KS <= 8) {
           cand = {0, 1};
-        } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
+        } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE || st.family == F_MULTI) {
           cand = {0, 1};
         }
         double best = 1e30;
@@ -1518,6 +1663,34 @@ static int enqueue_forward(vbt_model* m, const uint8_t* frames_dev, int B, hipSt
     }
   }
   VBT_HIP_CHECK(hipGetLastError());
+  m->last_B = B;
+  return VBT_OK;
+}
+
+// Forward = eager launches, or (small batches: the 120-odd launches are host-bound) replay of a captured hipGraph.
+static int forward(vbt_model* m, const uint8_t* frames_dev, int B, hipStream_t st, float* boxes, float* scores, float* classes,
+                   int* counts) {
+  if (B > m->graph_max_batch || !m->cap_stream) return enqueue_forward(m, frames_dev, B, st, boxes, scores, classes, counts, nullptr);
+  vbt_model::GraphKey key{frames_dev, boxes, scores, classes, counts, B};
+  auto it = m->graphs.find(key);
+  if (it == m->graphs.end()) {
+    if (m->graphs.size() >= 256) {  // bounded cache
+      for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+      m->graphs.clear();
+    }
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    VBT_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_forward(m, frames_dev, B, m->cap_stream, boxes, scores, classes, counts, nullptr);
+    hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return VBT_ERR_HIP; }
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return VBT_ERR_HIP; }
+    it = m->graphs.emplace(key, ge).first;
+  }
+  VBT_HIP_CHECK(hipGraphLaunch(it->second, st));
   m->last_B = B;
   return VBT_OK;
 }
@@ -1623,6 +1796,11 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
       if (!ok) { set_error("cannot create side streams"); return fail(VBT_ERR_HIP); }
     }
   }
+  {
+    const char* gm = getenv("VBT_GRAPH_MAX_BATCH");
+    m->graph_max_batch = (m->flags & VBT_MODEL_NO_GRAPH) ? 0 : (gm ? atoi(gm) : 8);
+    if (m->graph_max_batch > 0 && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) m->cap_stream = nullptr;
+  }
   if (!(m->flags & VBT_MODEL_NO_AUTOTUNE)) autotune(m);
   finalize_plan(m);
   *out = m;
@@ -1636,6 +1814,8 @@ void vbt_model_destroy(vbt_model* m) {
     if (m->ev_join[k]) (void)hipEventDestroy(m->ev_join[k]);
   }
   if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   for (void* p : m->owned) (void)hipFree(p);
   (void)hipFree(m->arena); (void)hipFree(m->frames_stage); (void)hipFree(m->out_boxes);
   (void)hipFree(m->out_scores); (void)hipFree(m->out_classes); (void)hipFree(m->out_counts);
@@ -1659,7 +1839,7 @@ int vbt_detect_async(vbt_model* m, const uint8_t* frames_dev, int B, void* strea
                      int32_t* counts) {
   if (!m || !frames_dev || !boxes || !scores || !classes || !counts) { set_error("vbt_detect_async: NULL argument"); return VBT_ERR_ARG; }
   if (B < 1 || B > m->max_batch) { set_error("vbt_detect: batch %d outside 1..%d", B, m->max_batch); return VBT_ERR_CAPACITY; }
-  return enqueue_forward(m, frames_dev, B, (hipStream_t)stream, boxes, scores, classes, counts, nullptr);
+  return forward(m, frames_dev, B, (hipStream_t)stream, boxes, scores, classes, counts);
 }
 
 int vbt_detect(vbt_model* m, const uint8_t* frames, int B, int frames_on_device, void* stream, float* boxes, float* scores,
@@ -1677,7 +1857,7 @@ int vbt_detect(vbt_model* m, const uint8_t* frames, int B, int frames_on_device,
   float *db = boxes, *ds = scores, *dc = classes;
   int* dn = counts;
   if (!outputs_on_device) { db = m->out_boxes; ds = m->out_scores; dc = m->out_classes; dn = m->out_counts; }
-  int rc = enqueue_forward(m, fd, B, st, db, ds, dc, dn, nullptr);
+  int rc = forward(m, fd, B, st, db, ds, dc, dn);
   if (rc) return rc;
   if (!outputs_on_device) {
     const int md = m->hdr.max_detections;

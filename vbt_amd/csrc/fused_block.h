@@ -64,10 +64,8 @@ constexpr int FB_EST = 80;  // E tile bytes per pixel (64 + 16: bank spread, 16-
 constexpr int FB_DST = 72;  // D tile bytes per pixel
 
 template <int KK, int S, int NBP, bool EXPAND, bool MDW>
-__global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+__device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, unsigned char* fb_smem) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
-  int tile = blockIdx.x;
   const int tx = tile % a.tiles_x;
   tile /= a.tiles_x;
   const int ty = tile % a.tiles_y;
@@ -362,6 +360,28 @@ __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
   }
 }
 
+
+template <int KK, int S, int NBP, bool EXPAND, bool MDW>
+__global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem_dyn[];
+  fused_block_body<KK, S, NBP, EXPAND, MDW>(a, blockIdx.x, fb_smem_dyn);
+}
+
+// Several independent problems (e.g. the same head layer on all 5 pyramid levels of both heads) in ONE grid:
+// a workgroup finds its problem from the cumulative tile counts and runs the same body.
+struct MultiTiles {
+  int n;
+  int start[13];  // start[p] = first workgroup of problem p, start[n] = grid size
+};
+template <int KK, int S, int NBP, bool EXPAND, bool MDW>
+__global__ __launch_bounds__(256) void fused_block_multi_kernel(const FusedArgs* __restrict__ args, MultiTiles mt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem_dyn[];
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < 12; i++)
+    if (i < mt.n && (int)blockIdx.x >= mt.start[i]) p = i;
+  fused_block_body<KK, S, NBP, EXPAND, MDW>(args[p], (int)blockIdx.x - mt.start[p], fb_smem_dyn);
+}
 
 // ------------------------------------------------------------------------------------------
 // LDS-tiled depthwise conv (stand-alone): the depthwise stage above with a chunk-parallel grid.
