@@ -65,6 +65,14 @@ __device__ __forceinline__ unsigned pack4_u8f(float a, float b, float c, float d
   v = __builtin_amdgcn_cvt_pk_u8_f32(d, 3, v);
   return v ^ 0x80808080u;
 }
+// acc already contains the bias (accumulators are initialised with it)
+__device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, const Rq& q) {
+  return pack4_u8f(rq_u8((float)acc[0], mu.x, q), rq_u8((float)acc[1], mu.y, q), rq_u8((float)acc[2], mu.z, q), rq_u8((float)acc[3], mu.w, q));
+}
+// exact n / d for 0 <= n < 2^20, 1 <= d <= 4096 without the ~40-instruction integer division
+__device__ __forceinline__ int fdiv_small(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
+__device__ __forceinline__ v4i v4i_from(const int4& b) { return (v4i){b.x, b.y, b.z, b.w}; }
+
 __device__ __forceinline__ unsigned rq_pack_i(const v4i& acc, const int4& b, const float4& mu, const Rq& q) {
   return pack4_u8f(rq_u8((float)(acc[0] + b.x), mu.x, q), rq_u8((float)(acc[1] + b.y), mu.y, q),
                    rq_u8((float)(acc[2] + b.z), mu.z, q), rq_u8((float)(acc[3] + b.w), mu.w, q));
@@ -168,7 +176,8 @@ __global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x,
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[i][t] = (v4i){0, 0, 0, 0};
   const int8_t* p = x + min(m0 + r, M - 1) * K + 8 * g;
-  for (int ks = 0; ks < KS; ks++) {
+#pragma unroll 4
+  for (int ks = 0; ks < KS; ks++) {  // unrolled so that the loads of several k-steps are in flight together
     long av = *(const long*)(p + 32 * ks);
 #pragma unroll
     for (int i = 0; i < NBT; i++) {
@@ -712,6 +721,9 @@ struct Step {
   int family;
   // conv
   long* wp = nullptr;      // packed MFMA weights (device)
+  long* wdm = nullptr;     // depthwise: matrix-pipe (diagonal-embedded) weights
+  int* bdm = nullptr;      // depthwise: bias folded for raw int8 inputs, padded to 64
+  float* mdm = nullptr;    // depthwise: multipliers padded to 64
   float* wf = nullptr;     // depthwise weights as float [k*k][C] (device)
   int* bias = nullptr;     // folded bias (device, padded)
   float* mult = nullptr;   // multipliers (device, padded)
@@ -1261,6 +1273,30 @@ static int build_plan(vbt_model* m) {
         }
         int rc;
         if ((rc = upload(m, wf, &s.wf)) || (rc = upload(m, bias, &s.bias)) || (rc = upload(m, mult, &s.mult))) return rc;
+        {  // matrix-pipe form (see make_fused)
+          const int Cp = (C + 63) / 64 * 64, KT = (kk + 1) / 2;
+          std::vector<long> wdm((size_t)(Cp / 64) * 4 * KT * 64, 0);
+          std::vector<int> biasm(Cp, 0);
+          std::vector<float> multm(Cp, 0.0f);
+          int8_t* wb = (int8_t*)wdm.data();
+          for (int ch = 0; ch < Cp / 64; ch++)
+            for (int cg = 0; cg < 4; cg++)
+              for (int mi = 0; mi < KT; mi++)
+                for (int lane = 0; lane < 64; lane++) {
+                  int i = lane & 15, g = lane >> 4, c = 64 * ch + 16 * cg + i, tap = 2 * mi + (g >> 1);
+                  for (int j = 0; j < 8; j++) {
+                    int cp = 8 * (g & 1) + j;
+                    wb[((((size_t)(ch * 4 + cg) * KT + mi) * 64 + lane) * 8) + j] = (tap < kk && cp == i && c < C) ? w[(size_t)tap * C + c] : 0;
+                  }
+                }
+          for (int c = 0; c < C; c++) {
+            long sw = 0;
+            for (int t = 0; t < kk; t++) sw += w[(size_t)t * C + c];
+            biasm[c] = (int)((long)bq[c] - (long)zx * sw);
+            multm[c] = mu[c];
+          }
+          if ((rc = upload(m, wdm, &s.wdm)) || (rc = upload(m, biasm, &s.bdm)) || (rc = upload(m, multm, &s.mdm))) return rc;
+        }
         s.weight_bytes = (double)kk * C;
         s.macs_per_frame = out_el * kk;
       } else {
@@ -1393,9 +1429,10 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       int C = to.c;
       unsigned pb = (unsigned)((128 + ti.zero_point) & 255);
       unsigned pad4 = pb | (pb << 8) | (pb << 16) | (pb << 24);
-      if (s.variant == 100) {  // LDS-tiled, chunk-parallel
+      if (s.variant == 100 || s.variant == 101) {  // LDS-tiled, chunk-parallel (101: depthwise on the matrix pipe)
         DwTileArgs a;
         a.x = x; a.out = out; a.wf = s.wf; a.bias = s.bias; a.mult = s.mult;
+        a.wdm = s.wdm; a.bdm = s.bdm; a.mdm = s.mdm;
         a.H = ti.h; a.W = ti.w; a.C = C; a.OH = to.h; a.OW = to.w; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
         choose_tile(to.h, to.w, op.k, op.stride, false, &a.TX, &a.TY);
         a.tiles_x = (to.w + a.TX - 1) / a.TX;
@@ -1406,7 +1443,11 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         const int NPh = ((TXp - 1) * op.stride + op.k) * ((a.TY - 1) * op.stride + op.k);
         dim3 grid((unsigned)((long)B * a.tiles_x * a.tiles_y), (unsigned)((C + 63) / 64));
         const int lds = NPh * 80;
-#define DW_LAUNCH(KK, S) dw_tile_kernel<KK, S><<<grid, 256, lds, st>>>(a)
+#define DW_LAUNCH(KK, S)                                                          \
+  do {                                                                            \
+    if (s.variant == 101) dw_tile_kernel<KK, S, true><<<grid, 256, lds, st>>>(a);  \
+    else dw_tile_kernel<KK, S, false><<<grid, 256, lds, st>>>(a);                  \
+  } while (0)
         if (op.k == 3 && op.stride == 1) DW_LAUNCH(3, 1);
         else if (op.k == 3 && op.stride == 2) DW_LAUNCH(3, 2);
         else if (op.k == 5 && op.stride == 1) DW_LAUNCH(5, 1);
@@ -1507,13 +1548,25 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const OpRec& dop = m->ops[s.d_op];
       dim3 grid((unsigned)((long)B * a.tiles_x * a.tiles_y));
       const bool ex = s.family == F_MBCONV;
-      const bool mdw = s.variant != 0;  // variant 0: depthwise on the VALU; default / 1: on the matrix pipe
+      // (the tile option of the variant is applied below, before the launch macros use `grid` / `lds_bytes`)
+      // variant bit 0: depthwise on the matrix pipe (default) / VALU; bits 1..: 0 = heuristic tile, 1 = half-height tile
+      const int var = s.variant < 0 ? 1 : s.variant;
+      const bool mdw = var & 1;
+      int lds_bytes = s.lds_bytes;
+      if ((var >> 1) == 1 && a.TY >= 2) {
+        a.TY = (a.TY + 1) / 2;
+        a.tiles_y = (a.OH + a.TY - 1) / a.TY;
+        const int TXp_ = (a.TX + 3) & ~3;
+        const int NPh_ = ((TXp_ - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
+        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + (s.family == F_MBCONV ? NPh_ * FB_EST : 0) + 64 * FB_DST;
+        grid = dim3((unsigned)((long)B * a.tiles_x * a.tiles_y));
+      }
 #define FB_LAUNCH(KK, S, NBP)                                                                              \
   do {                                                                                                     \
-    if (ex && mdw) fused_block_kernel<KK, S, NBP, true, true><<<grid, 256, s.lds_bytes, st>>>(a);           \
-    else if (ex) fused_block_kernel<KK, S, NBP, true, false><<<grid, 256, s.lds_bytes, st>>>(a);            \
-    else if (mdw) fused_block_kernel<KK, S, NBP, false, true><<<grid, 256, s.lds_bytes, st>>>(a);           \
-    else fused_block_kernel<KK, S, NBP, false, false><<<grid, 256, s.lds_bytes, st>>>(a);                   \
+    if (ex && mdw) fused_block_kernel<KK, S, NBP, true, true><<<grid, 256, lds_bytes, st>>>(a);           \
+    else if (ex) fused_block_kernel<KK, S, NBP, true, false><<<grid, 256, lds_bytes, st>>>(a);            \
+    else if (mdw) fused_block_kernel<KK, S, NBP, false, true><<<grid, 256, lds_bytes, st>>>(a);           \
+    else fused_block_kernel<KK, S, NBP, false, false><<<grid, 256, lds_bytes, st>>>(a);                   \
   } while (0)
 #define FB_NBP(KK, S)                                      \
   do {                                                     \
@@ -1593,10 +1646,12 @@ static void autotune(vbt_model* m) {
           cand = {0};
           for (int r : {1, 2, 4, 8, 16})
             if (r <= m->tensors[op.output].h) cand.push_back(r);
-          if (m->tensors[op.output].c % 8 == 0) cand.push_back(100);
+          if (m->tensors[op.output].c % 8 == 0) { cand.push_back(100); cand.push_back(101); }
         } else if (st.family == F_PW && st.KS <= 8) {
           cand = {0, 1};
-        } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE || st.family == F_MULTI) {
+        } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
+          cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
+        } else if (st.family == F_MULTI) {
           cand = {0, 1};
         }
         double best = 1e30;

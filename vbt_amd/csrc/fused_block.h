@@ -74,6 +74,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   const int TXp = (a.TX + 3) & ~3;
   const int HWx = (TXp - 1) * S + KK, HWy = (a.TY - 1) * S + KK, NPh = HWx * HWy;
   const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
+  const float rcp_hwx = 1.0f / (float)HWx, rcp_txp = 1.0f / (float)TXp;
   unsigned char* T0 = fb_smem;
   unsigned char* E = T0 + ((NPh * a.T0S + 15) & ~15);
   unsigned char* D = E + (EXPAND ? NPh * FB_EST : 0);
@@ -163,7 +164,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
     for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
       int p = pg * 16 + r;
       int pc = min(p, NPh - 1);
-      int hy = pc / HWx, hx = pc - hy * HWx;
+      int hy = fdiv_small(pc, rcp_hwx), hx = pc - hy * HWx;
       int iy = iy0 + hy, ix = ix0 + hx;
       if (!(iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)) oob_mask |= 1u << i;
       if (p >= NPh) tail_mask |= 1u << i;
@@ -185,7 +186,8 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 #pragma unroll
     for (int pg = 0; pg < 4; pg++) {
       int slot = pg * 16 + r;
-      int py_ = min(slot / TXp, a.TY - 1), px_ = slot - (slot / TXp) * TXp;
+      int sq = fdiv_small(slot, rcp_txp);
+      int py_ = min(sq, a.TY - 1), px_ = slot - sq * TXp;
       hbase[pg] = (py_ * S) * HWx + px_ * S;
     }
   }
@@ -207,9 +209,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
         const int pc = min(p, NPh - 1);
         v4i ea[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) ea[t] = (v4i){0, 0, 0, 0};
+        for (int t = 0; t < 4; t++) ea[t] = v4i_from(eb[t]);
         const unsigned char* brow = T0 + pc * a.T0S + 8 * g;
         const long* w = a.we + (long)c * a.KSe * 4 * 64 + lane;
+#pragma unroll 2
         for (int ks = 0; ks < a.KSe; ks++) {
           long bv = *(const long*)(brow + 32 * ks);
 #pragma unroll
@@ -218,7 +221,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
         unsigned d[4];
 #pragma unroll
         for (int t = 0; t < 4; t++)
-          d[t] = rq_pack_i(ea[t], eb[t], em[t], a.rqe);
+          d[t] = rq_pack_b(ea[t], em[t], a.rqe);
         if ((oob_mask >> i) & 1u) { d[0] = zeb; d[1] = zeb; d[2] = zeb; d[3] = zeb; }
         if (!((tail_mask >> i) & 1u)) *(uint4*)(E + p * FB_EST + 16 * g) = make_uint4(d[0], d[1], d[2], d[3]);
       }
@@ -242,7 +245,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       const int hi_half = g >> 1;
 #pragma unroll
       for (int pg = 0; pg < 4; pg++) {
-        v4i dq = {0, 0, 0, 0};
+        v4i dq = v4i_from(bqm);
         const unsigned char* pb = lane_base + hbase[pg] * est;
 #pragma unroll
         for (int mi = 0; mi < KT; mi++) {
@@ -253,7 +256,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
           long bv = *(const long*)(pb + (hi_half ? offb : offa));
           dq = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bv, dq, 0, 0, 0);
         }
-        *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_i(dq, bqm, mum, a.rqd);
+        *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dq, mum, a.rqd);
       }
     } else if (dw_active) {
       const unsigned char* Ein = EXPAND ? E + 4 * cq : T0 + 64 * c + 4 * cq;
@@ -314,7 +317,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 
   // ---- epilogue: requantise, optional residual ADD with the block input (centre of T0), store ----
   const int slot = wave * 16 + r;
-  const int py = slot / TXp, px = slot - py * TXp;
+  const int py = fdiv_small(slot, rcp_txp), px = slot - py * TXp;
   const int oy = oy0 + py, ox = ox0 + px;
   if (py < a.TY && px < a.TX && oy < a.OH && ox < a.OW) {
     const unsigned char* skip = T0 + ((py + a.pad_t) * HWx + (px + a.pad_l)) * a.T0S;  // S == 1 when has_res
@@ -396,11 +399,14 @@ struct DwTileArgs {
   const float* wf;   // [k*k][C]
   const int* bias;   // folded
   const float* mult;
+  const long* wdm;   // matrix-pipe form [chunk][cg][m][lane] (MDW)
+  const int* bdm;    // bias folded for raw int8 inputs, padded to 64-channel chunks
+  const float* mdm;  // multipliers padded to 64-channel chunks
   int H, W, C, OH, OW, pad_t, pad_l, TX, TY, tiles_x, tiles_y, zx;
   Rq rq;
 };
 
-template <int KK, int S>
+template <int KK, int S, bool MDW>
 __global__ __launch_bounds__(256) void dw_tile_kernel(DwTileArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dt_smem[];
   constexpr int TS = 80;  // bytes per halo pixel (64 channels + pad)
@@ -432,6 +438,42 @@ __global__ __launch_bounds__(256) void dw_tile_kernel(DwTileArgs a) {
       hx += pstep;
       while (hx >= HWx) { hx -= HWx; hy++; }
     }
+  }
+  if constexpr (MDW) {
+    // depthwise on the matrix pipe (see fused_block_body): wave = 16-channel group, 4 slot groups of 16 pixels
+    constexpr int KT = (KK * KK + 1) / 2;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const long* wm = a.wdm + ((long)(blockIdx.y * 4 + wave) * KT) * 64 + lane;
+    long wreg[KT];
+#pragma unroll
+    for (int mi = 0; mi < KT; mi++) wreg[mi] = wm[mi * 64];
+    const int cbase = c0 + 16 * wave + 4 * g;
+    const int4 bqm = *(const int4*)(a.bdm + cbase);
+    const float4 mum = *(const float4*)(a.mdm + cbase);
+    const float rcp_txp = 1.0f / (float)TXp;
+    __syncthreads();
+    if (16 * wave >= cvalid) return;
+    const unsigned char* lane_base = dt_smem + 16 * wave + 8 * (g & 1);
+    const int hi_half = g >> 1;
+#pragma unroll
+    for (int pg = 0; pg < 4; pg++) {
+      const int slot = pg * 16 + r;
+      const int sq = fdiv_small(slot, rcp_txp);
+      const int py = min(sq, a.TY - 1), px = slot - sq * TXp;
+      const unsigned char* pb = lane_base + ((py * S) * HWx + px * S) * TS;
+      v4i dq = v4i_from(bqm);
+#pragma unroll
+      for (int mi = 0; mi < KT; mi++) {
+        const int ta = 2 * mi, tb = (2 * mi + 1 < KK * KK) ? 2 * mi + 1 : 2 * mi;
+        const int offa = ((ta / KK) * HWx + (ta % KK)) * TS, offb = ((tb / KK) * HWx + (tb % KK)) * TS;
+        long bv = *(const long*)(pb + (hi_half ? offb : offa));
+        dq = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bv, dq, 0, 0, 0);
+      }
+      const int oy = oy0 + sq, ox = ox0 + px;
+      if (sq < a.TY && px < a.TX && oy < a.OH && ox < a.OW && cbase < a.C)
+        *(unsigned*)(a.out + ((b * a.OH + oy) * (long)a.OW + ox) * a.C + cbase) = rq_pack_b(dq, mum, a.rq);
+    }
+    return;
   }
   const int cq = tid & 15, strip = tid >> 4;
   const int nsx = TXp >> 2;
