@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+# The kernel plan tuned on an MI355X at B = 64 is pinned so that every run (and the committed rocprofv3 / PMC
+# summaries under profiles/) executes the same kernels; a different batch size or missing file re-tunes.
+os.environ.setdefault("VBT_PLAN_FILE", os.path.join(ROOT, "profiles", "plan_lite0"))
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
 MODEL = os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm")
 
 
@@ -179,8 +183,15 @@ def main():
         s = stats[fam]
         per_launch_s = ms[fam] * 1e-3 / s.launches
         achieved = (s.algorithmic_bytes / s.launches) / per_launch_s
+        traffic = None      # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same plan (profiles/)
+        try:
+            tj = json.load(open(TRAFFIC_JSON))
+            if tj.get("batch") == n and s.name.decode() in tj["families"] and tj["families"][s.name.decode()]["launches"] == s.launches:
+                traffic = tj["families"][s.name.decode()]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "hbm", "kernel": s.name.decode(), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK, "traffic": None, "launches_per_step": s.launches,
+                    "frac": achieved / HBM_PEAK, "traffic": traffic, "launches_per_step": s.launches,
                     "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": s.algorithmic_bytes / s.launches,
                     "families_ms_per_step": {stats[i].name.decode(): round(ms[i], 4) for i in range(cnt.value)},
                     "whole_net_algorithmic_GBps": sum(stats[i].algorithmic_bytes for i in range(cnt.value)) /

@@ -195,6 +195,66 @@ __global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x,
   }
 }
 
+// variant C: large K on FEW pixels (low-resolution project convs): the 4 waves of a workgroup share the same
+// 16 pixels and split K in four; partial accumulators meet in LDS, then each wave requantises one 16-channel
+// tile of every 64-channel block.  Quarter-length serial K loop, 4x the workgroups of variant B.
+template <int NBT>
+__global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x, const long* __restrict__ wp, Epi e,
+                                                   int8_t* __restrict__ out, long M, int K, int KS, int N, int NB) {
+  __shared__ v4i red[4][NBT * 4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const long m0 = (long)blockIdx.x * 16;
+  const int nb0 = blockIdx.y * NBT;
+  v4i acc[NBT][4];
+#pragma unroll
+  for (int i = 0; i < NBT; i++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[i][t] = (v4i){0, 0, 0, 0};
+  const int8_t* p = x + min(m0 + r, M - 1) * K + 8 * g;
+  const int per = (KS + 3) >> 2;
+  const int k0 = wave * per, k1 = min(k0 + per, KS);
+#pragma unroll 3
+  for (int ks = k0; ks < k1; ks++) {
+    long av = *(const long*)(p + 32 * ks);
+#pragma unroll
+    for (int i = 0; i < NBT; i++) {
+      int nb = min(nb0 + i, NB - 1);
+      const long* w = wp + ((long)(nb * KS + ks) * 4) * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], av, acc[i][t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NBT; i++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) red[wave][i * 4 + t][lane] = acc[i][t];
+  __syncthreads();
+  const long m = m0 + r;
+  // wave w finishes tile t = w of every block: lane -> 4 channels (64 nb + 16 g + 4 t + j) of pixel r
+#pragma unroll
+  for (int i = 0; i < NBT; i++) {
+    const int nb = nb0 + i, t = wave;
+    const int c0 = nb * 64 + 16 * g + 4 * t;
+    if (nb < NB && c0 < N && m < M) {
+      v4i s = red[0][i * 4 + t][lane];
+#pragma unroll
+      for (int w2 = 1; w2 < 4; w2++) {
+        v4i o = red[w2][i * 4 + t][lane];
+        s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+      }
+      int4 b = *(const int4*)(e.bias + c0);
+      float4 mu = *(const float4*)(e.mult + c0);
+      unsigned d = rq_pack_i(s, b, mu, e.rq);
+      int8_t* o = out + m * N + c0;
+      if ((N & 3) == 0) *(unsigned*)o = d;
+      else
+        for (int j = 0; j < 4; j++)
+          if (c0 + j < N) o[j] = (int8_t)(d >> (8 * j));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // stem: 3x3 stride-2 conv on the uint8 frame as one 16x16x32 MFMA K-step.  The 27 taps are
 // laid out per lane group g: g<3 -> the first 8 bytes (px0 RGB, px1 RGB, px2 RG) of kernel row g,
@@ -1407,6 +1467,11 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
           case 7: launch_pw_a<7>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
           default: launch_pw_a<8>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
         }
+      } else if (s.variant == 2) {  // split-K over the 4 waves of a workgroup
+        int nbt = std::min(s.NB, 2);
+        dim3 grid((unsigned)((M + 15) / 16), (unsigned)((s.NB + nbt - 1) / nbt));
+        if (nbt == 1) pw_c_kernel<1><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB);
+        else pw_c_kernel<2><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB);
       } else {
         long waves = (M + 15) / 16;
         unsigned gx = (unsigned)((waves + 3) / 4);
@@ -1649,6 +1714,8 @@ static void autotune(vbt_model* m) {
           if (m->tensors[op.output].c % 8 == 0) { cand.push_back(100); cand.push_back(101); }
         } else if (st.family == F_PW && st.KS <= 8) {
           cand = {0, 1};
+        } else if (st.family == F_PW) {
+          cand = {-1, 2};
         } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
           cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
         } else if (st.family == F_MULTI) {
@@ -1685,6 +1752,42 @@ static void autotune(vbt_model* m) {
     }
   }
   (void)hipDeviceSynchronize();
+}
+
+// Plan cache: "<ngroups>" then per group "<chosen> <nsteps> <variant>..." for the chosen alternative.
+static bool load_plan(vbt_model* m, const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return false;
+  int ng = 0;
+  bool ok = fscanf(f, "%d", &ng) == 1 && ng == (int)m->groups.size();
+  std::vector<std::pair<int, std::vector<int>>> sel;
+  for (int gi = 0; ok && gi < ng; gi++) {
+    int ch = 0, ns = 0;
+    ok = fscanf(f, "%d %d", &ch, &ns) == 2 && ch >= 0 && ch < (int)m->groups[gi].alts.size() && ns == (int)m->groups[gi].alts[ch].steps.size();
+    std::vector<int> v(ok ? ns : 0);
+    for (int i = 0; ok && i < ns; i++) ok = fscanf(f, "%d", &v[i]) == 1;
+    sel.push_back({ch, v});
+  }
+  fclose(f);
+  if (!ok) return false;
+  for (int gi = 0; gi < ng; gi++) {
+    m->groups[gi].chosen = sel[gi].first;
+    Alt& a = m->groups[gi].alts[sel[gi].first];
+    for (size_t i = 0; i < a.steps.size(); i++) a.steps[i].variant = sel[gi].second[i];
+  }
+  return true;
+}
+static void save_plan(const vbt_model* m, const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return;
+  fprintf(f, "%d\n", (int)m->groups.size());
+  for (const Group& g : m->groups) {
+    const Alt& a = g.alts[g.chosen];
+    fprintf(f, "%d %d", g.chosen, (int)a.steps.size());
+    for (const Step& st : a.steps) fprintf(f, " %d", st.variant);
+    fprintf(f, "\n");
+  }
+  fclose(f);
 }
 
 static int enqueue_forward(vbt_model* m, const uint8_t* frames_dev, int B, hipStream_t st, float* boxes, float* scores,
@@ -1856,7 +1959,16 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
     m->graph_max_batch = (m->flags & VBT_MODEL_NO_GRAPH) ? 0 : (gm ? atoi(gm) : 8);
     if (m->graph_max_batch > 0 && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) m->cap_stream = nullptr;
   }
-  if (!(m->flags & VBT_MODEL_NO_AUTOTUNE)) autotune(m);
+  if (!(m->flags & VBT_MODEL_NO_AUTOTUNE)) {
+    // VBT_PLAN_FILE: reuse a previously tuned plan (keeps profiled and un-profiled runs on the same kernels)
+    const char* pf = getenv("VBT_PLAN_FILE");
+    char path[1024];
+    if (pf) snprintf(path, sizeof(path), "%s.b%d.f%d", pf, max_batch, m->flags);
+    if (!pf || !load_plan(m, path)) {
+      autotune(m);
+      if (pf) save_plan(m, path);
+    }
+  }
   finalize_plan(m);
   *out = m;
   return VBT_OK;
