@@ -115,12 +115,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal knobs (not used by the driver): VBT_BENCH_SAME_DEVICE=1 puts every rank on GPU 0 and
+    # VBT_BENCH_BACKEND=gloo gathers through host memory, so the N > 1 code path can run on a 1-GPU box.
+    if os.environ.get("VBT_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("VBT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective buffers live
 
     from vbt_amd import _lib
     from vbt_amd.track import Pipeline
@@ -154,10 +163,10 @@ def main():
         rec[c, 0], rec[c, 1], rec[c, 2] = best, st["rows"], len(ph)
         rec[c, 3:3 + 6 * min(len(ph), 32)] = ph[:32].reshape(-1)
     if dist is not None:                                             # the one exchange of the path: RCCL all-gather
-        mine = torch.from_numpy(rec).to(dev)
-        allrec = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=dev)
+        mine = torch.from_numpy(rec).to(cdev)
+        allrec = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=cdev)   # concatenated layout
         dist.all_gather_into_tensor(allrec, mine)
-        rec_all = allrec.cpu().numpy()
+        rec_all = allrec.cpu().numpy().reshape(world, *rec.shape)
     else:
         rec_all = rec[None]
     torch.cuda.synchronize()
@@ -166,7 +175,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     overflow = sum(pipe.tracker.status(c)["overflow"] for c in range(n))
