@@ -82,55 +82,96 @@ def export_dataframe(data, src_name, model_path, df_dir=None, write=True):
 
 
 class Pipeline:
-    """n clips processed frame-wise: step(frames[n,H,W,3] on the device) enqueues detect+NMS and one
-    tracker step for every clip on `stream`; finish() selects each clip's export id and runs the rep
-    analysis on the device.  Nothing leaves the GPU until rows()/phases() are read."""
+    """n clips processed frame-wise: step(frames[n,H,W,3] on the device) enqueues detect+NMS for this frame
+    set and the tracker step of the PREVIOUS one; finish() drains, selects each clip's export id and runs the
+    rep analysis on the device.  Nothing leaves the GPU until rows()/phases() are read.
+
+    Software pipeline over HIP streams: the detector is stateless, so `depth` consecutive steps are in
+    flight at once, each on its own stream with its own model instance (activation arena) and output
+    buffers; the OC-SORT steps stay strictly ordered on a dedicated tracker stream and trail the detector,
+    chained by events (detector(t) -> tracker(t) -> slot reuse).  At batch 64 a single forward leaves the
+    GPU latency-bound (measured: throughput = B / (0.65 ms + 16.8 us * B)); two or more forwards in flight
+    recover most of that without changing the per-step batch."""
 
     def __init__(self, model_path, n_clips, max_frames, fps=60.0, detection_treshold=0.5, device=0, rows_per_frame=4,
-                 plate_diameter=0.45):
+                 plate_diameter=0.45, depth=None):
+        import torch
         self.n = int(n_clips)
         self.fps = np.broadcast_to(np.asarray(fps, np.float64), (self.n,)).copy()
         self.thr = float(detection_treshold)
         self.plate_diameter = plate_diameter
-        self.interpreter = Interpreter(model_path, device=device, max_batch=self.n)
-        self.tracker = MultiClipTracker(self.n, int(max_frames) * rows_per_frame + 3 * 25, max_age=MAX_AGE,   # frames 1-3 may emit 25 rows each
-                                        asso_func="diou",
-                                        iou_threshold=0.1, device=device)
-        self.frame_count = 0
+        self.depth = int(depth if depth is not None else os.environ.get("VBT_PIPELINE_DEPTH", "3"))
+        self.depth = max(1, min(self.depth, 8))
         self._dev = device
-        self._bufs = None
-        self._times = np.zeros(self.n, np.float64)
-
-    def _alloc(self):
-        import torch
-        dev = torch.device(f"cuda:{self._dev}")
+        self._torch = torch
+        tdev = torch.device(f"cuda:{device}")
+        self.interpreters = [Interpreter(model_path, device=device, max_batch=self.n) for _ in range(self.depth)]
+        self.interpreter = self.interpreters[0]
+        self.tracker = MultiClipTracker(self.n, int(max_frames) * rows_per_frame + 3 * 25, max_age=MAX_AGE,   # frames 1-3 may emit 25 rows each
+                                        asso_func="diou", iou_threshold=0.1, device=device)
+        self.frame_count = 0
         n = self.n
-        self._bufs = (torch.empty((n, 25, 4), dtype=torch.float32, device=dev), torch.empty((n, 25), dtype=torch.float32, device=dev),
-                      torch.empty((n, 25), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.int32, device=dev))
+        self._bufs = [(torch.empty((n, 25, 4), dtype=torch.float32, device=tdev), torch.empty((n, 25), dtype=torch.float32, device=tdev),
+                       torch.empty((n, 25), dtype=torch.float32, device=tdev), torch.empty((n,), dtype=torch.int32, device=tdev))
+                      for _ in range(self.depth)]
+        self._times = [np.zeros(n, np.float64) for _ in range(self.depth)]
+        self._det_streams = [torch.cuda.Stream(device=tdev) for _ in range(self.depth)]
+        self._trk_stream = torch.cuda.Stream(device=tdev)
+        self._ev_in = [torch.cuda.Event() for _ in range(self.depth)]
+        self._ev_det = [torch.cuda.Event() for _ in range(self.depth)]
+        self._ev_trk = [None] * self.depth          # tracker finished reading slot k's outputs
+        self._pending = []                          # slots whose tracker step has not been enqueued yet
+
+    def _enqueue_tracker(self, k):
+        T = self._trk_stream
+        T.wait_event(self._ev_det[k])
+        b, s, c, cnt = self._bufs[k]
+        _lib.check(_lib.lib().vbt_tracker_update_from_detections(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
+                                                                 self._times[k].ctypes.data, self.thr, T.cuda_stream))
+        ev = self._torch.cuda.Event()
+        ev.record(T)
+        self._ev_trk[k] = ev
 
     def step(self, frames_dev_ptr, stream=None):
-        """frames_dev_ptr: device pointer of uint8 [n,H,W,3] (frame `frame_count+1` of every clip)."""
-        if self._bufs is None:
-            self._alloc()
-        b, s, c, k = self._bufs
+        """frames_dev_ptr: device pointer of uint8 [n,H,W,3] (frame `frame_count+1` of every clip), valid on the
+        caller's current torch stream."""
+        torch = self._torch
+        k = self.frame_count % self.depth
         self.frame_count += 1
-        np.divide(float(self.frame_count), self.fps, out=self._times)          # time = frame_count / fps (track.py:169)
-        L = _lib.lib()
-        _lib.check(L.vbt_detect_async(self.interpreter.handle, frames_dev_ptr, self.n, stream, b.data_ptr(), s.data_ptr(),
-                                      c.data_ptr(), k.data_ptr()))
-        _lib.check(L.vbt_tracker_update_from_detections(self.tracker.handle, b.data_ptr(), s.data_ptr(), k.data_ptr(),
-                                                        self._times.ctypes.data, self.thr, stream))
+        S = self._det_streams[k]
+        self._ev_in[k].record(torch.cuda.current_stream())           # frames are ready once the caller's stream gets here
+        S.wait_event(self._ev_in[k])
+        if self._ev_trk[k] is not None:
+            S.wait_event(self._ev_trk[k])                            # the tracker is done with this slot's previous outputs
+        np.divide(float(self.frame_count), self.fps, out=self._times[k])      # time = frame_count / fps (track.py:169)
+        b, s, c, cnt = self._bufs[k]
+        _lib.check(_lib.lib().vbt_detect_async(self.interpreters[k].handle, frames_dev_ptr, self.n, S.cuda_stream, b.data_ptr(),
+                                               s.data_ptr(), c.data_ptr(), cnt.data_ptr()))
+        self._ev_det[k].record(S)
+        self._pending.append(k)
+        while len(self._pending) >= self.depth:                      # keep depth-1 detector steps ahead of the tracker
+            self._enqueue_tracker(self._pending.pop(0))
+
+    def _drain(self):
+        while self._pending:
+            self._enqueue_tracker(self._pending.pop(0))
 
     def finish(self, stream=None):
-        self.tracker.finish(self.plate_diameter, stream=stream)
+        self._drain()
+        self.tracker.finish(self.plate_diameter, stream=self._trk_stream.cuda_stream)
+        self._trk_stream.synchronize()
 
     def rows(self, clip):
+        self._drain()
+        self._trk_stream.synchronize()
         return self.tracker.rows(clip)
 
     def phases(self, clip):
         return self.tracker.phases(clip)
 
     def detections(self):
-        """Last step's detector outputs (host copies) - for tests."""
-        b, s, c, k = self._bufs
-        return b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), k.cpu().numpy()
+        """Most recent step's detector outputs (host copies) - for tests."""
+        k = (self.frame_count - 1) % self.depth
+        self._det_streams[k].synchronize()
+        b, s, c, cnt = self._bufs[k]
+        return b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), cnt.cpu().numpy()
