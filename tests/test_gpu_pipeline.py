@@ -103,6 +103,32 @@ def test_preprocess_resize_matches_oracle():
         assert np.array_equal(got, ref(img, (h, w))), ((H, W), (h, w))
 
 
+def test_pipeline_source_resolution_frames(oracle_lib, model_path):
+    """N2: 416x416 BGR source frames (the size of the reference's data/test images) resized + channel-swapped on the
+    device inside the pipeline == oracle preprocess (reference odt.py:10-19, track.py:171) + oracle detector."""
+    import torch
+    from oracle.preprocess import preprocess_image as ref_pre
+    from vbt_amd.track import Pipeline
+    rng = np.random.default_rng(11)
+    n, T = 3, 4
+    src = rng.integers(0, 256, (T, n, 416, 416, 3), dtype=np.uint8)
+    src = (src // 32 * 32 + np.repeat(np.repeat(rng.integers(0, 32, (T, n, 52, 52, 3), dtype=np.uint8), 8, 2), 8, 3)).astype(np.uint8)
+    fd = torch.from_numpy(src).to("cuda:0")
+    pipe = Pipeline(model_path, n, max_frames=T, fps=30.0)
+    st = torch.cuda.current_stream().cuda_stream
+    got = []
+    for t in range(T):
+        pipe.step(fd[t].data_ptr(), st, src_hw=(416, 416), swap_rb=True)
+        got.append(pipe.detections())
+    pipe.finish(st)
+    want_frames = np.stack([np.stack([ref_pre(src[t, c], (320, 320), swap_rb=True)[0] for c in range(n)]) for t in range(T)])
+    ob, os_, oc, on = oracle_lib.run_batch(model_path, want_frames.reshape(-1, 320, 320, 3), threads=8)
+    ob, os_, on = ob.reshape(T, n, 25, 4), os_.reshape(T, n, 25), on.reshape(T, n)
+    for t in range(T):
+        b, s, c, k = got[t]
+        assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t]), t
+
+
 def test_errors_are_loud(model_path):
     from vbt_amd import _lib
     from vbt_amd.interpreter import Interpreter

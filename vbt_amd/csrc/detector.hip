@@ -65,17 +65,26 @@ __device__ __forceinline__ unsigned pack4_u8f(float a, float b, float c, float d
   v = __builtin_amdgcn_cvt_pk_u8_f32(d, 3, v);
   return v ^ 0x80808080u;
 }
-// acc already contains the bias (accumulators are initialised with it)
+// acc already contains the bias (accumulators are initialised with it).  The multiply and the offset add use the
+// packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32: two IEEE single ops per instruction, same results).
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, const Rq& q) {
-  return pack4_u8f(rq_u8((float)acc[0], mu.x, q), rq_u8((float)acc[1], mu.y, q), rq_u8((float)acc[2], mu.z, q), rq_u8((float)acc[3], mu.w, q));
+  v2f t0 = (v2f){(float)acc[0], (float)acc[1]} * (v2f){mu.x, mu.y};
+  v2f t1 = (v2f){(float)acc[2], (float)acc[3]} * (v2f){mu.z, mu.w};
+  v2f r0 = {__builtin_amdgcn_fmed3f(__builtin_rintf(t0.x), q.lo_f, q.hi_f), __builtin_amdgcn_fmed3f(__builtin_rintf(t0.y), q.lo_f, q.hi_f)};
+  v2f r1 = {__builtin_amdgcn_fmed3f(__builtin_rintf(t1.x), q.lo_f, q.hi_f), __builtin_amdgcn_fmed3f(__builtin_rintf(t1.y), q.lo_f, q.hi_f)};
+  const v2f off = {q.off, q.off};
+  r0 = r0 + off;
+  r1 = r1 + off;
+  return pack4_u8f(r0.x, r0.y, r1.x, r1.y);
 }
 // exact n / d for 0 <= n < 2^20, 1 <= d <= 4096 without the ~40-instruction integer division
 __device__ __forceinline__ int fdiv_small(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
 __device__ __forceinline__ v4i v4i_from(const int4& b) { return (v4i){b.x, b.y, b.z, b.w}; }
 
 __device__ __forceinline__ unsigned rq_pack_i(const v4i& acc, const int4& b, const float4& mu, const Rq& q) {
-  return pack4_u8f(rq_u8((float)(acc[0] + b.x), mu.x, q), rq_u8((float)(acc[1] + b.y), mu.y, q),
-                   rq_u8((float)(acc[2] + b.z), mu.z, q), rq_u8((float)(acc[3] + b.w), mu.w, q));
+  const v4i a2 = {acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w};
+  return rq_pack_b(a2, mu, q);
 }
 
 struct Epi {  // requantisation parameters of one conv

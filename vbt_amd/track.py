@@ -121,6 +121,7 @@ class Pipeline:
         self._ev_det = [torch.cuda.Event() for _ in range(self.depth)]
         self._ev_trk = [None] * self.depth          # tracker finished reading slot k's outputs
         self._pending = []                          # slots whose tracker step has not been enqueued yet
+        self._resized = [None] * self.depth         # per-slot network-resolution frames (source-resolution input)
 
     def _enqueue_tracker(self, k):
         T = self._trk_stream
@@ -132,9 +133,11 @@ class Pipeline:
         ev.record(T)
         self._ev_trk[k] = ev
 
-    def step(self, frames_dev_ptr, stream=None):
+    def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False):
         """frames_dev_ptr: device pointer of uint8 [n,H,W,3] (frame `frame_count+1` of every clip), valid on the
-        caller's current torch stream."""
+        caller's current torch stream.  src_hw=(H, W) of the source frames when they are not at the network
+        resolution: the bilinear resize + truncating cast of reference odt.py:10-19 (and, with swap_rb, the
+        BGR->RGB of track.py:171) then run on the device, on the slot's stream, ahead of the detector."""
         torch = self._torch
         k = self.frame_count % self.depth
         self.frame_count += 1
@@ -143,6 +146,13 @@ class Pipeline:
         S.wait_event(self._ev_in[k])
         if self._ev_trk[k] is not None:
             S.wait_event(self._ev_trk[k])                            # the tracker is done with this slot's previous outputs
+        size = int(self.interpreter.get_input_details()[0]["shape"][1])
+        if src_hw is not None and (tuple(src_hw) != (size, size) or swap_rb):
+            if self._resized[k] is None:
+                self._resized[k] = torch.empty((self.n, size, size, 3), dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
+            _lib.check(_lib.lib().vbt_resize_frames(frames_dev_ptr, self.n, int(src_hw[0]), int(src_hw[1]), 1, self._resized[k].data_ptr(),
+                                                    size, size, 1, int(bool(swap_rb)), self._dev, S.cuda_stream))
+            frames_dev_ptr = self._resized[k].data_ptr()
         np.divide(float(self.frame_count), self.fps, out=self._times[k])      # time = frame_count / fps (track.py:169)
         b, s, c, cnt = self._bufs[k]
         _lib.check(_lib.lib().vbt_detect_async(self.interpreters[k].handle, frames_dev_ptr, self.n, S.cuda_stream, b.data_ptr(),
