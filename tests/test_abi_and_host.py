@@ -115,3 +115,47 @@ def test_two_rank_gather_over_gloo(tmp_path):
     import json
     got = json.loads(outs[0][0].strip().splitlines()[-1])
     assert [g[0] for g in got] == list(range(7)) and {g[2] for g in got} == {0, 1}
+
+
+WORKER_FRAMES = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["VBT_ROOT"])
+import numpy as np, torch.distributed as dist
+from vbt_amd.shard import frame_chunks, pack_detection_records, gather_detection_records, unpack_detection_records
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+T = 37
+s, e = frame_chunks(T, world)[rank]
+f = np.arange(s, e)
+boxes = (f[:, None, None] + np.arange(25)[None, :, None] * 0.01 + np.arange(4)[None, None, :] * 0.001).astype(np.float32)
+scores = (f[:, None] * 0.5 + np.arange(25)[None, :] / 256.0).astype(np.float32)
+counts = (f % 26).astype(np.int32)
+allrec = gather_detection_records(pack_detection_records(boxes, scores, counts), T, dist)
+b, sc, c = unpack_detection_records(allrec)
+ok = len(c) == T and np.array_equal(c, np.arange(T) % 26) and np.allclose(b[:, 0, 0], np.arange(T)) and np.allclose(sc[:, 3], np.arange(T) * 0.5 + 3 / 256)
+if rank == 0:
+    print(json.dumps({"ok": bool(ok), "frames": int(len(c))}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_frame_major_detection_records_over_gloo(tmp_path):
+    """SURVEY 8e, one long clip: ranks detect contiguous frame chunks, one all-gather returns the 504-byte
+    per-frame records in frame order (uneven chunks are padded)."""
+    from vbt_amd.shard import frame_chunks, records_to_tracker_inputs, pack_detection_records
+    assert frame_chunks(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)] and frame_chunks(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    script = tmp_path / "worker_frames.py"
+    script.write_text(WORKER_FRAMES)
+    env = dict(os.environ, VBT_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29654", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    assert json.loads(outs[0][0].strip().splitlines()[-1]) == {"ok": True, "frames": 37}
+    # threshold + reorder on the owner (reference odt.py:70-75,102-118)
+    boxes = np.zeros((2, 25, 4), np.float32); boxes[0, 0] = (0.1, 0.2, 0.3, 0.4); boxes[0, 1] = (0.5, 0.6, 0.7, 0.8)
+    scores = np.zeros((2, 25), np.float32); scores[0, :2] = (0.9, 0.4)
+    dets, cnt, times = records_to_tracker_inputs(pack_detection_records(boxes, scores, np.array([2, 0])), fps=30.0)
+    assert cnt.tolist() == [[1], [0]] and np.allclose(dets[0, 0, 0], (0.2, 0.1, 0.4, 0.3, 0.9, 0.0)) and np.allclose(times[:, 0], (1 / 30, 2 / 30))

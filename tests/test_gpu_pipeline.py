@@ -129,6 +129,35 @@ def test_pipeline_source_resolution_frames(oracle_lib, model_path):
         assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t]), t
 
 
+def test_frame_major_mode_equals_clip_mode(model_path):
+    """SURVEY 8e second mode on one long clip: detect contiguous frame chunks independently (as two ranks would),
+    exchange the 504-byte records, track on the owner == the fused per-frame pipeline on the same clip."""
+    import torch
+    from vbt_amd import shard, synth
+    from vbt_amd.interpreter import Interpreter
+    from vbt_amd.ocsort import MultiClipTracker
+    from vbt_amd.track import Pipeline
+    T = 21
+    frames = synth.clip_frames(33, 0, T)
+    recs = []
+    for s, e in shard.frame_chunks(T, 2):                               # each "rank" batches its whole chunk
+        it = Interpreter(model_path, max_batch=e - s)
+        b, sc, c, k = it.detect(frames[s:e])
+        recs.append(shard.pack_detection_records(b, sc, k))
+    dets, cnt, times = shard.records_to_tracker_inputs(np.concatenate(recs), fps=60.0)
+    mc = MultiClipTracker(1, 25 * T, max_age=30, asso_func="diou", iou_threshold=0.1)
+    mc.update_frames(dets, cnt, times)
+    pipe = Pipeline(model_path, 1, max_frames=T, fps=60.0, rows_per_frame=25)
+    fd = torch.from_numpy(frames).to("cuda:0")
+    for t in range(T):
+        pipe.step(fd[t:t + 1].data_ptr())
+    pipe.finish()
+    a, b2 = mc.rows(0), pipe.rows(0)
+    assert a["id"] == b2["id"] and len(a["id"]) > 0
+    for k in COLS:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b2[k])), k
+
+
 def test_errors_are_loud(model_path):
     from vbt_amd import _lib
     from vbt_amd.interpreter import Interpreter

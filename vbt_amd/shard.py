@@ -35,3 +35,72 @@ def gather_records(rec, dist, pad_to):
     dist.all_gather(out, block)
     rows = [o[1:1 + int(o[0, 0].item())].cpu().numpy() for o in out]
     return np.concatenate(rows, axis=0) if rows else np.zeros((0, k))
+
+
+# ---- frame-major mode: ONE long clip ----------------------------------------------
+# Detection has no state, so rank r detects the contiguous frame chunk r; tracking is sequential per clip, so
+# a single owner consumes all detections.  Exchange = one all-gather of fixed-size per-frame records
+# [25 x (4 box + 1 score) f32 + count] = 504 B/frame (latency-bound: 10 k frames = 5 MB in total).
+RECORD_FLOATS = 25 * 5 + 1
+
+
+def frame_chunks(n_frames, world):
+    """Contiguous, balanced [start, stop) per rank."""
+    base, rem = divmod(n_frames, world)
+    out, s = [], 0
+    for r in range(world):
+        e = s + base + (1 if r < rem else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def pack_detection_records(boxes, scores, counts):
+    """boxes [F,25,4], scores [F,25], counts [F] -> float32 records [F,126]."""
+    F = len(counts)
+    rec = np.zeros((F, RECORD_FLOATS), np.float32)
+    rec[:, :100] = np.asarray(boxes, np.float32).reshape(F, 100)
+    rec[:, 100:125] = np.asarray(scores, np.float32)
+    rec[:, 125] = np.asarray(counts, np.float32)
+    return rec
+
+
+def unpack_detection_records(rec):
+    rec = np.asarray(rec, np.float32)
+    return rec[:, :100].reshape(-1, 25, 4), rec[:, 100:125], rec[:, 125].astype(np.int32)
+
+
+def gather_detection_records(rec, n_frames, dist, device=None):
+    """rec: this rank's records for its chunk of frame_chunks(n_frames, world).  Returns all n_frames records in
+    frame order on every rank via ONE all_gather_into_tensor of equal (padded) blocks."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    chunks = frame_chunks(n_frames, world)
+    per = max(e - s for s, e in chunks)
+    block = torch.zeros((per, RECORD_FLOATS), dtype=torch.float32, device=device)
+    n = chunks[rank][1] - chunks[rank][0]
+    assert rec.shape == (n, RECORD_FLOATS)
+    if n:
+        block[:n] = torch.as_tensor(rec, dtype=torch.float32, device=device)
+    out = torch.empty((world * per, RECORD_FLOATS), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, block)
+    out = out.cpu().numpy().reshape(world, per, RECORD_FLOATS)
+    return np.concatenate([out[r, :chunks[r][1] - chunks[r][0]] for r in range(world)], axis=0)
+
+
+def records_to_tracker_inputs(rec, fps, threshold=0.5):
+    """Gathered records -> (dets [F,1,25,6] float64, counts [F,1], times [F,1]) for MultiClipTracker.update_frames:
+    threshold of reference odt.py:70-75 and reorder of odt.py:102-118, time = frame_count / fps (track.py:169)."""
+    boxes, scores, counts = unpack_detection_records(rec)
+    F = len(counts)
+    dets = np.zeros((F, 1, 25, 6), np.float64)
+    cnt = np.zeros((F, 1), np.int32)
+    for f in range(F):
+        k = 0
+        for i in range(counts[f]):
+            if scores[f, i] >= threshold:
+                dets[f, 0, k] = (boxes[f, i, 1], boxes[f, i, 0], boxes[f, i, 3], boxes[f, i, 2], scores[f, i], 0.0)
+                k += 1
+        cnt[f, 0] = k
+    times = ((np.arange(F, dtype=np.float64) + 1.0) / fps).reshape(F, 1)
+    return dets, cnt, times
