@@ -1001,7 +1001,10 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   {
     const int8_t* w = (const int8_t*)(m->blob.data() + pop.w_off);
     std::vector<long> wp;
-    pack_weights(w, tout.c, Ce, Cp / 32, ps.NB, nullptr, wp);
+    // the kernel instantiation covers nbp = {1,2,3,5} blocks and reads the weights of all of them: allocate (zero
+    // rows) up to nbp, otherwise a 4-block layer (e.g. Cout = 208 in Lite2) reads past the packed array
+    const int nbp_alloc = ps.NB <= 3 ? ps.NB : 5;
+    pack_weights(w, tout.c, Ce, Cp / 32, nbp_alloc, nullptr, wp);
     long* dwp;
     int rc;
     if ((rc = upload(m, wp, &dwp))) return rc;
