@@ -867,11 +867,34 @@ struct vbt_model {
 
 namespace vbt {
 
+// Debug "electric fence" (VBT_DEBUG_FENCE=1): every device buffer is placed so that it ENDS at the end of its own
+// 2 MiB-granular allocation; a kernel reading past the documented slack then touches unmapped memory and faults
+// instead of silently reading a neighbour.  Used once per model family by tests/tools, never in production.
+static bool fence_on() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VBT_DEBUG_FENCE"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+static hipError_t fenced_malloc(vbt_model* m, void** out, size_t bytes) {
+  if (!fence_on()) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) m->owned.push_back(*out);
+    return e;
+  }
+  const size_t G = 2u << 20;
+  size_t total = (bytes + G - 1) / G * G;
+  char* base = nullptr;
+  hipError_t e = hipMalloc((void**)&base, total);
+  if (e != hipSuccess) return e;
+  m->owned.push_back(base);
+  *out = base + ((total - bytes) & ~(size_t)255);   // keep 256-B alignment; the buffer ends <= 255 B before the fence
+  return hipSuccess;
+}
+
 template <typename T>
 static int upload(vbt_model* m, const std::vector<T>& h, T** d) {
   size_t bytes = std::max<size_t>(h.size() * sizeof(T), 16);
-  VBT_HIP_CHECK(hipMalloc((void**)d, bytes + 64));
-  m->owned.push_back(*d);
+  VBT_HIP_CHECK(fenced_malloc(m, (void**)d, bytes + 64));
   if (!h.empty()) VBT_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
   return VBT_OK;
 }
@@ -1933,13 +1956,13 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
     size_t bytes = (int)i == m->hdr.input_tensor ? 0 : m->telems[i] * max_batch;
     total += (bytes + 255) / 256 * 256 + 256;
   }
-  if (hipMalloc((void**)&m->arena, total + 4096) != hipSuccess) { set_error("hipMalloc(%zu) for activations failed", total); return fail(VBT_ERR_HIP); }
+  if (fenced_malloc(m, (void**)&m->arena, total + 4096) != hipSuccess) { set_error("hipMalloc(%zu) for activations failed", total); return fail(VBT_ERR_HIP); }
   (void)hipMemset(m->arena, 0, total + 4096);
   m->tptr.resize(m->tensors.size());
   for (size_t i = 0; i < m->tensors.size(); i++) m->tptr[i] = m->arena + off[i];
   size_t fbytes = (size_t)max_batch * m->hdr.image_size * m->hdr.image_size * 3;
   const int md = m->hdr.max_detections;
-  if (hipMalloc((void**)&m->frames_stage, fbytes + 64) != hipSuccess || hipMalloc((void**)&m->out_boxes, (size_t)max_batch * md * 16) != hipSuccess ||
+  if (fenced_malloc(m, (void**)&m->frames_stage, fbytes + 64) != hipSuccess || hipMalloc((void**)&m->out_boxes, (size_t)max_batch * md * 16) != hipSuccess ||
       hipMalloc((void**)&m->out_scores, (size_t)max_batch * md * 4) != hipSuccess || hipMalloc((void**)&m->out_classes, (size_t)max_batch * md * 4) != hipSuccess ||
       hipMalloc((void**)&m->out_counts, (size_t)max_batch * 4) != hipSuccess) {
     set_error("hipMalloc for staging buffers failed");
@@ -1996,7 +2019,7 @@ void vbt_model_destroy(vbt_model* m) {
   for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   for (void* p : m->owned) (void)hipFree(p);
-  (void)hipFree(m->arena); (void)hipFree(m->frames_stage); (void)hipFree(m->out_boxes);
+  (void)hipFree(m->out_boxes);  // arena and frames_stage are in `owned`
   (void)hipFree(m->out_scores); (void)hipFree(m->out_classes); (void)hipFree(m->out_counts);
   delete m;
 }
