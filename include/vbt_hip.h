@@ -169,6 +169,12 @@ int vbt_tracker_phases(vbt_tracker* t, int clip, int32_t* best_id, double* phase
 int vbt_analyze(const double* cols7, int T, int preprocess, int flush, double plate_diameter, double diff_threshold,
                 double min_distance, double* phases6, int cap, int* P, int device);
 
+/* Trailing / expanding window means of the columns of a row-major float64 table rows[T][ncols] (ncols <= 64),
+ * bit-identical to pandas `Series.rolling(window, center=False, min_periods=1).mean()` (windows[c] > 0) and
+ * `Series.expanding(min_periods=1).mean()` (windows[c] == 0); windows[c] < 0 copies column c.
+ * Replaces the smoothing of reference plot.py:90-95, kinovea.py:99-105 and qualysis.py:113-117. */
+int vbt_window_means(const double* rows, int T, int ncols, const int32_t* windows, double* out, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,63 @@
+"""GPU parity for a model that arrives as a `.tflite` flatbuffer (reference track.py:67,93): the HIP path on the imported
+graph (binary ADD chains, importer-derived multipliers and LUTs) against the oracle on the same imported container."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def imported(tmp_path_factory, model_path):
+    import export_tflite
+    from vbt_amd.tflite_import import convert
+    d = tmp_path_factory.mktemp("tfl")
+    tfl, vbtm = str(d / "lite0.tflite"), str(d / "lite0.vbtm")
+    export_tflite.export(model_path, tfl)
+    convert(tfl, vbtm)
+    return tfl, vbtm
+
+
+@pytest.mark.parametrize("flags", [1, 8, 0])
+def test_tflite_model_bit_exact(imported, oracle_lib, flags):
+    from vbt_amd import synth
+    from vbt_amd.interpreter import Interpreter
+    tfl, vbtm = imported
+    frames = np.concatenate([synth.clip_frames(s, 5 * s, 2) for s in range(2)])
+    det = oracle_lib.OracleDetector(vbtm)
+    it = Interpreter(model_path=tfl, max_batch=len(frames), flags=flags)       # the .tflite itself
+    assert it.num_tensors() == det.num_tensors
+    boxes, scores, classes, counts = it.detect(frames)
+    checked = 0
+    for b, f in enumerate(frames):
+        ob, os_, oc, on = det.run(f)
+        assert counts[b] == on and np.array_equal(scores[b], os_) and np.array_equal(boxes[b], ob)
+        for tid in range(1, it.num_tensors() - 1):
+            if it.materialized(tid):
+                checked += 1
+                assert np.array_equal(it.read_tensor(tid, len(frames))[b], det.tensor(tid)), (tid, b)
+    if flags == 1:
+        assert checked == len(frames) * (it.num_tensors() - 2)
+    else:
+        assert it.num_launches() < 120
+
+
+def test_cli_accepts_tflite(imported, tmp_path):
+    """`track --model x.tflite` end to end (reference track.py:67)."""
+    from click.testing import CliRunner
+    from vbt_amd import synth
+    from vbt_amd.cli import main
+    tfl, _ = imported
+    clip = tmp_path / "clip.npy"
+    np.save(str(clip), synth.clip_frames(3, 0, 12))
+    out = tmp_path / "dfs"
+    res = CliRunner().invoke(main, ["track", str(clip), "--model", tfl, "--df_dir", str(out), "--fps", "60", "--detection_treshold", "0.3"])
+    assert res.exit_code == 0, res.output
+    assert "rows" in res.output
+    files = os.listdir(out)
+    assert len(files) <= 1 and all(f.endswith("_lite0.pkl.gz") for f in files)

@@ -7,7 +7,10 @@
   python -m vbt_amd.cli analyze DF.pkl.gz... [--plate_diameter 0.45]
       reference plot.py:50-70,73-95,163-173 without the figure: parses {video}_id{N}_{model}.pkl.gz, applies the
       rolling(5)/expanding preprocessing and the VelocityTracker on the GPU, prints ROM and ACV per concentric rep.
-Option names (including the reference's `treshold` spelling) and defaults follow the reference.
+  python -m vbt_amd.cli validate [--kinovea_dir D | --qualysis_dir D] [--df_dir dfs] [--plate_diameter 0.45]
+      reference kinovea.py:29-38,57-172,203-215 / qualysis.py:29-38,57-187 without the figures: per export with a
+      matching {video}_id{N}_{model}.pkl.gz, MSE and Pearson r of x(t) and y(t) in metres, then the totals line.
+Option names (including the reference's `treshold` / `qualysis` spellings) and defaults follow the reference.
 """
 import os
 import re
@@ -81,6 +84,40 @@ def analyze(src, plate_diameter):
         click.echo(f"{video} (id {tid}, {model}): {len(phases)} phases, {len(reps)} concentric reps")
         for i, p in enumerate(reps, 1):
             click.echo(f"  rep {i}: t {p.time_start:.4f}-{p.time_end:.4f} s  ROM {p.rom:.6f} m  ACV {p.rom / p.duration:.6f} m/s")
+
+
+@main.command()
+@click.option("--kinovea_dir", default=None, help="Directory containing the kinovea exports (*.txt).")
+@click.option("--qualysis_dir", default=None, help="Directory containing the qualysis exports (*.tsv).")
+@click.option("--df_dir", default="dfs", show_default=True, help="Directory containing the dfs.")
+@click.option("--plate_diameter", default=0.45, show_default=True, type=float, help="Diameter of the weight plate used in meters.")
+def validate(kinovea_dir, qualysis_dir, df_dir, plate_diameter):
+    import glob
+    import pandas as pd
+    from . import validate as V
+    if (kinovea_dir is None) == (qualysis_dir is None):
+        raise click.UsageError("give exactly one of --kinovea_dir / --qualysis_dir")
+    source = "kinovea" if kinovea_dir is not None else "qualisys"
+    exports = sorted(glob.glob(os.path.join(kinovea_dir, "*.txt") if source == "kinovea" else os.path.join(qualysis_dir, "*.tsv")))
+    df_files = sorted(glob.glob(os.path.join(df_dir, "*.pkl.gz")))
+    rows_out = []
+    for ex in exports:
+        stem = os.path.basename(ex).split(".")[0]
+        match = next((x for x in df_files if os.path.basename(x).startswith(stem)), None)
+        if match is None:
+            click.echo(f"No matching df file found for: {ex}")                    # reference kinovea.py:62-64
+            continue
+        m = FILENAME_RE.match(os.path.basename(match))
+        if not m:
+            continue
+        video, tid, _ = m.groups()
+        df = pd.read_pickle(match).query(f"id == {tid}").sort_values(by="time")
+        rows = np.stack([df[c].to_numpy(np.float64) for c in ("time", "x", "y", "norm_plate_height", "norm_plate_width")], axis=1)
+        ref = V.read_kinovea(ex) if source == "kinovea" else V.read_qualisys(ex)
+        r = V.validate_pair(ref, rows, plate_diameter, source)
+        rows_out.append((video, r))
+        click.echo(f"{video}: MSEx {r['mse_x']:.4f}  MSEy {r['mse_y']:.4f}  r_x {r['r_x']:.4f}  r_y {r['r_y']:.4f}")
+    click.echo(f"Total MSEx = {sum(r['mse_x'] for _, r in rows_out)}, MSEy = {sum(r['mse_y'] for _, r in rows_out)}")
 
 
 if __name__ == "__main__":

@@ -833,6 +833,25 @@ __global__ __launch_bounds__(64) void analyze_kernel(const double* cols, const i
                 phases + (size_t)clip * MAXPH * 6, nph + clip);
 }
 
+// pandas rolling(window, min_periods=1).mean() (window > 0) / expanding(min_periods=1).mean() (window == 0) of every
+// column of a row-major [T][ncols] table; lane = column (plot.py:90-95, kinovea.py:99-105, qualysis.py:113-117).
+__global__ __launch_bounds__(64) void window_means_kernel(const double* rows, int T, int ncols, const int* windows, double* out) {
+  const int c = threadIdx.x;
+  if (c >= ncols) return;
+  const int w = windows[c];
+  RollMean r;
+  r.init();
+  for (int i = 0; i < T; i++) {
+    double v = rows[(size_t)i * ncols + c];
+    if (w >= 0) {
+      if (w > 0 && i >= w) r.remove(rows[(size_t)(i - w) * ncols + c]);
+      r.add(v);
+      v = r.mean();
+    }
+    out[(size_t)i * ncols + c] = v;
+  }
+}
+
 // end of clip: live tracks compete for the export id too; then gather the rows of the winner.
 __global__ __launch_bounds__(64) void select_gather_kernel(ClipState* states, const Row* rows, int rows_cap, double* cols, int* T,
                                                            int* best_ids) {
@@ -1116,6 +1135,30 @@ int vbt_analyze(const double* cols7, int T, int preprocess, int flush, double pl
   }
   (void)hipFree(dc); (void)hipFree(ds); (void)hipFree(dp); (void)hipFree(dn); (void)hipFree(dT);
   return rc;
+}
+
+int vbt_window_means(const double* rows, int T, int ncols, const int32_t* windows, double* out, int device) {
+  if (T < 0 || ncols < 1 || ncols > 64 || !windows || (T > 0 && (!rows || !out))) { set_error("vbt_window_means: bad argument"); return VBT_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_error("vbt_window_means: HIP device %d not available (%d visible) - no CPU fallback", device, ndev);
+    return VBT_ERR_HIP;
+  }
+  if (T == 0) return VBT_OK;
+  VBT_HIP_CHECK(hipSetDevice(device));
+  double *din = nullptr, *dout = nullptr;
+  int* dw = nullptr;
+  const size_t bytes = sizeof(double) * (size_t)T * ncols;
+  VBT_HIP_CHECK(hipMalloc((void**)&din, bytes));
+  VBT_HIP_CHECK(hipMalloc((void**)&dout, bytes));
+  VBT_HIP_CHECK(hipMalloc((void**)&dw, sizeof(int) * ncols));
+  VBT_HIP_CHECK(hipMemcpy(din, rows, bytes, hipMemcpyHostToDevice));
+  VBT_HIP_CHECK(hipMemcpy(dw, windows, sizeof(int) * ncols, hipMemcpyHostToDevice));
+  window_means_kernel<<<1, 64>>>(din, T, ncols, dw, dout);
+  hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dw);
+  if (e != hipSuccess) { set_error("window means kernel failed: %s", hipGetErrorString(e)); return VBT_ERR_HIP; }
+  return VBT_OK;
 }
 
 }  // extern "C"

@@ -24,8 +24,17 @@ class Interpreter:
         self.device = device
         self.max_batch = int(max_batch)
         self._h = ctypes.c_void_p()
-        _lib.check(_lib.lib().vbt_model_create_ex(self.model_path.encode(), device, self.max_batch, (flags if flags is not None else (int(os.environ.get('VBT_FUSION_FLAGS', '0')) if fuse else 1)),
-                                                  ctypes.byref(self._h)))
+        if flags is None:
+            flags = int(os.environ.get('VBT_FUSION_FLAGS', '0')) if fuse else 1
+        # --model may name a TFLite flatbuffer like the reference's (track.py:67): it is converted to the container
+        # format on the fly (vbt_amd/tflite_import.py); the library itself only parses containers.
+        from .tflite_import import as_container_path
+        path, temporary = as_container_path(self.model_path)
+        try:
+            _lib.check(_lib.lib().vbt_model_create_ex(path.encode(), device, self.max_batch, flags, ctypes.byref(self._h)))
+        finally:
+            if temporary:
+                os.unlink(path)
         shp = (ctypes.c_int * 4)()
         _lib.check(_lib.lib().vbt_model_input_shape(self._h, shp))
         self._shape = np.array([1, shp[1], shp[2], shp[3]], dtype=np.int32)
