@@ -123,6 +123,7 @@ __device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_
 }
 
 #include "fused_block.h"  // (inside namespace vbt)
+#include "stem_block.h"
 
 // ------------------------------------------------------------------------------------------
 // pointwise conv, variant A: K <= 256, activations of 16*MS pixels stay in registers while the
@@ -781,9 +782,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
-                                           "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node", "fused_heads_multi"};
+                                           "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node", "fused_heads_multi",
+                                           "fused_stem_block"};
 
 struct Step {
   int op;       // index into ops
@@ -809,6 +811,8 @@ struct Step {
   // F_MULTI: independent fused problems launched as one grid
   std::vector<Step> members;
   FusedArgs* d_multi = nullptr;
+  // F_STEMBLK: stem -> depthwise -> project in one kernel (op = project op, e_op = stem op)
+  StemBlockArgs sb;
 };
 
 // A group of consecutive graph ops with alternative realisations (all bit-identical); the planner keeps
@@ -1166,6 +1170,107 @@ static int batch_heads(vbt_model* m) {
   return VBT_OK;
 }
 
+// ---- network entry: STEM(3x3/2, 3 -> 32) -> DW(3x3/1) -> PW(32 -> <=16) as one kernel (stem_block.h) ----
+static bool stem_block_ok(const vbt_model* m, int si, const std::vector<int>& consumers) {
+  const int no = (int)m->ops.size();
+  if (si + 2 >= no) return false;
+  const OpRec& st = m->ops[si];
+  const OpRec& d = m->ops[si + 1];
+  const OpRec& p = m->ops[si + 2];
+  if (st.type != OP_STEM || d.type != OP_DW || p.type != OP_PW) return false;
+  const TensorRec& ti = m->tensors[st.inputs[0]];
+  const TensorRec& ts = m->tensors[st.output];
+  const TensorRec& td = m->tensors[d.output];
+  const TensorRec& to = m->tensors[p.output];
+  return st.k == 3 && st.stride == 2 && ti.c == 3 && ts.c == 32 && ti.w % 4 == 0 && d.inputs[0] == st.output && consumers[st.output] == 1 &&
+         d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && td.c == 32 && p.inputs[0] == d.output && consumers[d.output] == 1 &&
+         to.c <= 16 && to.c % 4 == 0;
+}
+
+static int make_stem_block(vbt_model* m, int si, Step* out) {
+  const OpRec& st = m->ops[si];
+  const OpRec& d = m->ops[si + 1];
+  const OpRec& p = m->ops[si + 2];
+  const TensorRec& ti = m->tensors[st.inputs[0]];
+  const TensorRec& ts = m->tensors[st.output];
+  const TensorRec& td = m->tensors[d.output];
+  const TensorRec& to = m->tensors[p.output];
+  Step s;
+  s.op = si + 2;
+  s.family = F_STEMBLK;
+  s.e_op = si;
+  s.d_op = si + 1;
+  s.p_op = si + 2;
+  StemBlockArgs& a = s.sb;
+  a.frames = nullptr; a.out = nullptr;
+  a.H = ti.h; a.W = ti.w; a.SH = ts.h; a.SW = ts.w; a.Cout = to.c;
+  a.spad_t = st.pad_t; a.spad_l = st.pad_l;
+  a.tiles_x = (ts.w + 15) / 16; a.tiles_y = (ts.h + 15) / 16;
+  a.in_pad4 = (unsigned)((ti.zero_point + 128) & 255) * 0x01010101u;
+  a.zs4 = (unsigned)(ts.zero_point & 255) * 0x01010101u;
+  a.rqs = make_rq(ts.zero_point, st.act_min, st.act_max);
+  a.rqd = make_rq(td.zero_point, d.act_min, d.act_max);
+  a.rqp = make_rq(to.zero_point, p.act_min, p.act_max);
+  int rc;
+  {  // stem: K index 8kg + j -> kernel row kg, byte j of its 9 (kg < 3); (row j, byte 8) for kg == 3, j < 3
+    const int8_t* w = (const int8_t*)(m->blob.data() + st.w_off);
+    const int32_t* bq = (const int32_t*)(m->blob.data() + st.b_off);
+    const float* mu = (const float*)(m->blob.data() + st.m_off);
+    std::vector<long> ws(2 * 64, 0);
+    int8_t* o = (int8_t*)ws.data();
+    for (int t = 0; t < 2; t++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int i = lane & 15, kg = lane >> 4, co = 8 * (i >> 2) + 4 * t + (i & 3);
+        for (int j = 0; j < 8; j++) {
+          const int f = kg < 3 ? kg * 9 + j : (j < 3 ? j * 9 + 8 : -1);
+          o[((size_t)t * 64 + lane) * 8 + j] = f >= 0 ? w[(size_t)co * 27 + f] : 0;
+        }
+      }
+    std::vector<int> bs(32);
+    std::vector<float> ms(mu, mu + 32);
+    for (int c = 0; c < 32; c++) {
+      long sw = 0;
+      for (int k = 0; k < 27; k++) sw += w[(size_t)c * 27 + k];
+      bs[c] = (int)((long)bq[c] - (long)ti.zero_point * sw);
+    }
+    long* dws; int* dbs; float* dms;
+    if ((rc = upload(m, ws, &dws)) || (rc = upload(m, bs, &dbs)) || (rc = upload(m, ms, &dms))) return rc;
+    a.ws = dws; a.bs = dbs; a.ms = dms;
+  }
+  const Step& ds = m->op_steps[si + 1];  // matrix-pipe depthwise weights of the dw op
+  a.wdm = ds.wdm; a.bdm = ds.bdm; a.mdm = ds.mdm;
+  {  // project: row i = cout i, K = 32
+    const int8_t* w = (const int8_t*)(m->blob.data() + p.w_off);
+    const int32_t* bq = (const int32_t*)(m->blob.data() + p.b_off);
+    const float* mu = (const float*)(m->blob.data() + p.m_off);
+    std::vector<long> wp(64, 0);
+    int8_t* o = (int8_t*)wp.data();
+    std::vector<int> bp(16, 0);
+    std::vector<float> mp(16, 0.0f);
+    for (int lane = 0; lane < 64; lane++) {
+      const int i = lane & 15, kg = lane >> 4;
+      for (int j = 0; j < 8; j++) o[(size_t)lane * 8 + j] = i < to.c ? w[(size_t)i * 32 + 8 * kg + j] : 0;
+    }
+    for (int c = 0; c < to.c; c++) {
+      long sw = 0;
+      for (int k = 0; k < 32; k++) sw += w[(size_t)c * 32 + k];
+      bp[c] = (int)((long)bq[c] - (long)td.zero_point * sw);
+      mp[c] = mu[c];
+    }
+    long* dwp; int* dbp; float* dmp;
+    if ((rc = upload(m, wp, &dwp)) || (rc = upload(m, bp, &dbp)) || (rc = upload(m, mp, &dmp))) return rc;
+    a.wp = dwp; a.bp = dbp; a.mp = dmp;
+  }
+  for (int k = 0; k < 3; k++) {
+    const Step& os = m->op_steps[si + k];
+    s.alg_bytes_per_frame += os.alg_bytes_per_frame;
+    s.weight_bytes += os.weight_bytes;
+    s.macs_per_frame += os.macs_per_frame;
+  }
+  *out = s;
+  return VBT_OK;
+}
+
 static int fuse_plan(vbt_model* m) {
   const int no = (int)m->ops.size();
   std::vector<int> consumers(m->tensors.size(), 0);
@@ -1242,6 +1347,30 @@ static int fuse_plan(vbt_model* m) {
         a2.hidden.push_back(m->ops[i + 1].output);
         g.alts.push_back(a2);
       }
+      g.chosen = (int)g.alts.size() - 1;
+      m->groups.push_back(g);
+      i += 3;
+      continue;
+    }
+    if (fuse_sep && !(m->flags & VBT_MODEL_NO_STEM_FUSION) && stem_block_ok(m, i, consumers)) {
+      Alt unf, a1, a2;
+      for (int k = 0; k < 3; k++) unf.steps.push_back(m->op_steps[i + k]);
+      g.alts.push_back(unf);
+      a1.steps.push_back(m->op_steps[i]);
+      Step s1, s2;
+      int rc = make_fused(m, -1, i + 1, i + 2, -1, &s1);
+      if (rc) return rc;
+      if (s1.lds_bytes <= 64 * 1024) {
+        a1.steps.push_back(s1);
+        a1.hidden.push_back(m->ops[i + 1].output);
+        g.alts.push_back(a1);
+      }
+      rc = make_stem_block(m, i, &s2);
+      if (rc) return rc;
+      a2.steps.push_back(s2);
+      a2.hidden.push_back(op.output);
+      a2.hidden.push_back(m->ops[i + 1].output);
+      g.alts.push_back(a2);
       g.chosen = (int)g.alts.size() - 1;
       m->groups.push_back(g);
       i += 3;
@@ -1683,6 +1812,13 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       else FB_NBP(5, 2);
 #undef FB_NBP
 #undef FB_LAUNCH
+      break;
+    }
+    case F_STEMBLK: {
+      StemBlockArgs a = s.sb;
+      a.frames = frames;
+      a.out = out;
+      stem_block_kernel<<<dim3((unsigned)((long)B * a.tiles_x * a.tiles_y)), 256, 0, st>>>(a);
       break;
     }
     case F_POST: {
