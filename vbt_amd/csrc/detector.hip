@@ -124,6 +124,7 @@ __device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_
 
 #include "fused_block.h"  // (inside namespace vbt)
 #include "stem_block.h"
+#include "image_block.h"
 
 // ------------------------------------------------------------------------------------------
 // pointwise conv, variant A: K <= 256, activations of 16*MS pixels stay in registers while the
@@ -813,6 +814,8 @@ struct Step {
   FusedArgs* d_multi = nullptr;
   // F_STEMBLK: stem -> depthwise -> project in one kernel (op = project op, e_op = stem op)
   StemBlockArgs sb;
+  // F_MBCONV on a low-resolution map: per-chunk weight records of the whole-image kernel (data == nullptr: not built)
+  ImageBundle ib = {nullptr, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // A group of consecutive graph ops with alternative realisations (all bit-identical); the planner keeps
@@ -1070,6 +1073,51 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
       s.weight_bytes += m->op_steps[oi].weight_bytes;
       s.macs_per_frame += m->op_steps[oi].macs_per_frame;
     }
+  if (expand && tin.h * tin.w <= 400 && tout.h * tout.w <= 400) {
+    // whole-image kernel (image_block.h): one contiguous record per 64-channel chunk
+    const OpRec& eop = m->ops[e_op];
+    const int8_t* we = (const int8_t*)(m->blob.data() + eop.w_off);
+    const int32_t* bqe = (const int32_t*)(m->blob.data() + eop.b_off);
+    const float* mue = (const float*)(m->blob.data() + eop.m_off);
+    const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
+    const int32_t* bqd = (const int32_t*)(m->blob.data() + dop.b_off);
+    const float* mud = (const float*)(m->blob.data() + dop.m_off);
+    const int8_t* wpj = (const int8_t*)(m->blob.data() + pop.w_off);
+    const int KSe = a.KSe, NB = (tout.c + 63) / 64, nch = Cp / 64;
+    std::vector<long> pe, pp;
+    pack_weights(we, Ce, tin.c, KSe, nch, nullptr, pe);
+    pack_weights(wpj, tout.c, Ce, Cp / 32, NB, nullptr, pp);
+    ImageBundle ib;
+    ib.o_be = KSe * 2048; ib.o_me = ib.o_be + 256; ib.o_dw = ib.o_me + 256;
+    ib.o_bd = ib.o_dw + ((kk * 64 + 15) & ~15); ib.o_md = ib.o_bd + 256; ib.o_wp = ib.o_md + 256;
+    ib.bytes = ib.o_wp + NB * 4096;
+    std::vector<unsigned char> rec((size_t)nch * ib.bytes, 0);
+    for (int c = 0; c < nch; c++) {
+      unsigned char* R = rec.data() + (size_t)c * ib.bytes;
+      memcpy(R, pe.data() + (size_t)c * KSe * 4 * 64, (size_t)KSe * 2048);
+      int* be = (int*)(R + ib.o_be); float* me = (float*)(R + ib.o_me);
+      int* bd = (int*)(R + ib.o_bd); float* md = (float*)(R + ib.o_md);
+      for (int i = 0; i < 64; i++) {
+        const int ch = 64 * c + i;
+        if (ch >= Ce) continue;
+        long swe = 0, swd = 0;
+        for (int k = 0; k < tin.c; k++) swe += we[(size_t)ch * tin.c + k];
+        for (int t = 0; t < kk; t++) { swd += wd[(size_t)t * Ce + ch]; R[ib.o_dw + t * 64 + i] = (unsigned char)wd[(size_t)t * Ce + ch]; }
+        be[i] = (int)((long)bqe[ch] - (long)tin.zero_point * swe);
+        me[i] = mue[ch];
+        bd[i] = (int)((long)bqd[ch] - (long)tdin.zero_point * swd);
+        md[i] = mud[ch];
+      }
+      for (int nb = 0; nb < NB; nb++)
+        for (int k2 = 0; k2 < 2; k2++)
+          memcpy(R + ib.o_wp + (size_t)((nb * 2 + k2) * 4) * 512, pp.data() + ((size_t)(nb * (Cp / 32) + 2 * c + k2) * 4) * 64, 4 * 512);
+    }
+    unsigned char* drec;
+    int rc;
+    if ((rc = upload(m, rec, &drec))) return rc;
+    ib.data = drec;
+    s.ib = ib;
+  }
   *out = s;
   return VBT_OK;
 }
@@ -1587,6 +1635,35 @@ static void launch_pw_a(int MS, dim3 grid, hipStream_t st, const int8_t* x, cons
 }
 
 // Launches one plan step for frames [boff, boff + B) of the batch (every tensor is batch-major).
+// Whole-image MBConv kernel (image_block.h): eligibility and launch geometry.
+struct ImageGeom { int PW, PH, NB, maxu, lds; bool ok; };
+static ImageGeom image_geom(const vbt_model* m, const Step& s) {
+  ImageGeom g{0, 0, 0, 0, 0, false};
+  if (s.family != F_MBCONV) return g;
+  const FusedArgs& a = s.fa;
+  const OpRec& dop = m->ops[s.d_op];
+  const int HW = a.H * a.W, OHW = a.OH * a.OW;
+  if (HW > 400 || OHW > 400) return g;
+  g.PH = std::max((a.OH - 1) * dop.stride + dop.k, a.pad_t + a.H);
+  g.PW = std::max((a.OW - 1) * dop.stride + dop.k, a.pad_l + a.W);
+  g.NB = (a.Cout + 63) / 64;
+  const int NPGo = (OHW + 15) / 16;
+  const int units = (NPGo * g.NB + IB_WAVES - 1) / IB_WAVES;
+  g.maxu = units <= 2 ? 2 : units <= 3 ? 3 : 4;
+  g.lds = ((HW * a.T0S + 15) & ~15) + g.PH * g.PW * FB_EST + NPGo * 16 * FB_DST + s.ib.bytes;
+  g.ok = s.ib.data != nullptr && units <= 4 && g.lds <= 160 * 1024 && s.ib.bytes <= 16 * IB_NPF * IB_THREADS;
+  return g;
+}
+template <int KK, int S, int MAXU>
+static void launch_image_block(const FusedArgs& a, const ImageBundle& wb, const ImageGeom& g, int B, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_image_kernel<KK, S, MAXU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  mbconv_image_kernel<KK, S, MAXU><<<dim3((unsigned)B), IB_THREADS, g.lds, st>>>(a, wb, g.PW, g.PH, g.NB);
+}
+
 static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const uint8_t* frames, float* boxes, float* scores,
                        float* classes, int* counts, int boff = 0) {
   const OpRec& op = m->ops[s.op];
@@ -1779,8 +1856,24 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const bool ex = s.family == F_MBCONV;
       // (the tile option of the variant is applied below, before the launch macros use `grid` / `lds_bytes`)
       // variant bit 0: depthwise on the matrix pipe (default) / VALU; bits 1..: 0 = heuristic tile, 1 = half-height tile
-      const int var = s.variant < 0 ? 1 : s.variant;
+      const int var = s.variant < 0 ? (((m->flags & VBT_MODEL_IMAGE_BLOCKS) && image_geom(m, s).ok) ? 5 : 1) : s.variant;
       const bool mdw = var & 1;
+      if (var & 4) {  // one workgroup per image (low-resolution blocks)
+        const ImageGeom ig = image_geom(m, s);
+        if (!ig.ok) { set_error("fused_mbconv: whole-image variant not applicable"); return VBT_ERR_ARG; }
+#define IB_LAUNCH(KK, S)                                                    \
+  do {                                                                      \
+    if (ig.maxu == 2) launch_image_block<KK, S, 2>(a, s.ib, ig, B, st);           \
+    else if (ig.maxu == 3) launch_image_block<KK, S, 3>(a, s.ib, ig, B, st);      \
+    else launch_image_block<KK, S, 4>(a, s.ib, ig, B, st);                        \
+  } while (0)
+        if (dop.k == 3 && dop.stride == 1) IB_LAUNCH(3, 1);
+        else if (dop.k == 3 && dop.stride == 2) IB_LAUNCH(3, 2);
+        else if (dop.k == 5 && dop.stride == 1) IB_LAUNCH(5, 1);
+        else IB_LAUNCH(5, 2);
+#undef IB_LAUNCH
+        break;
+      }
       int lds_bytes = s.lds_bytes;
       if ((var >> 1) == 1 && a.TY >= 2) {
         a.TY = (a.TY + 1) / 2;
@@ -1889,6 +1982,7 @@ static void autotune(vbt_model* m) {
           cand = {-1, 2};
         } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
           cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
+          if (image_geom(m, st).ok) cand.push_back(5);  // one workgroup per image
         } else if (st.family == F_MULTI) {
           cand = {0, 1};
         }
@@ -1898,6 +1992,8 @@ static void autotune(vbt_model* m) {
           Step t = st;
           t.variant = v;
           double ms = time_step(m, t, B, reps);
+          if (getenv("VBT_AUTOTUNE_VERBOSE") && cand.size() > 1 && atoi(getenv("VBT_AUTOTUNE_VERBOSE")) > 1)
+            fprintf(stderr, "[autotune]   op %d %s v%d %.1fus\n", st.op, kFamilyName[st.family], v, ms * 1e3);
           if (ms < best) { best = ms; bestv = v; }
         }
         st.variant = bestv;
