@@ -74,3 +74,31 @@ def test_batch_tail_and_single_frame(model_path, frames, oracle_run):
     b3 = it.detect(frames[:3])
     for b in range(3):
         assert b3[3][b] == outs[b][3] and np.array_equal(b3[0][b], outs[b][0])
+
+
+def test_explicit_clamps_bit_exact(tmp_path, model_path, oracle_lib, frames):
+    """The synthetic model's activation ranges all end at the int8 limits, where the requantisation leaves the clamp
+    to the saturating u8 conversion.  Narrow the range of two convs in three so the explicit-clamp path runs too."""
+    from vbt_amd.container import Container
+    from vbt_amd.interpreter import Interpreter
+    raw = bytearray(open(model_path, "rb").read())
+    c = Container(model_path)
+    ops = np.frombuffer(raw, dtype=c.ops.dtype, count=len(c.ops), offset=128 + 32 * len(c.tensors))
+    n = 0
+    for i, r in enumerate(ops):
+        if int(r["type"]) in (1, 2, 3) and i % 3 != 0:
+            r["act_min"], r["act_max"] = max(int(r["act_min"]), -101 + i % 7), min(int(r["act_max"]), 96 - i % 5)
+            n += 1
+    assert n > 100
+    path = str(tmp_path / "clamped.vbtm")
+    open(path, "wb").write(bytes(raw))
+    det = oracle_lib.OracleDetector(path)
+    for flags in (1, 8, 0):
+        it = Interpreter(path, max_batch=2, flags=flags)
+        boxes, scores, classes, counts = it.detect(frames[:2])
+        for b in range(2):
+            ob, os_, oc, on = det.run(frames[b])
+            assert counts[b] == on and np.array_equal(scores[b], os_) and np.array_equal(boxes[b], ob)
+            for tid in range(1, it.num_tensors() - 1):
+                if it.materialized(tid):
+                    assert np.array_equal(it.read_tensor(tid, 2)[b], det.tensor(tid)), (flags, tid)

@@ -52,8 +52,11 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
 // it, and one XOR 0x80808080 per dword turns the four bytes back into int8.
 struct Rq {
   float lo_f, hi_f, off;  // lo - zp, hi - zp, zp + 128
+  int full;               // lo == -128 && hi == 127: the clamp is the [0,255] saturation of v_cvt_pk_u8_f32 itself
 };
-__host__ __device__ inline Rq make_rq(int zp, int lo, int hi) { return Rq{(float)(lo - zp), (float)(hi - zp), (float)(zp + 128)}; }
+__host__ __device__ inline Rq make_rq(int zp, int lo, int hi) {
+  return Rq{(float)(lo - zp), (float)(hi - zp), (float)(zp + 128), (lo <= -128 && hi >= 127) ? 1 : 0};
+}
 __device__ __forceinline__ float rq_u8(float accf, float mult, const Rq& q) {
   float r = __builtin_rintf(accf * mult);
   return __builtin_amdgcn_fmed3f(r, q.lo_f, q.hi_f) + q.off;
@@ -71,9 +74,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, const Rq& q) {
   v2f t0 = (v2f){(float)acc[0], (float)acc[1]} * (v2f){mu.x, mu.y};
   v2f t1 = (v2f){(float)acc[2], (float)acc[3]} * (v2f){mu.z, mu.w};
+  const v2f off = {q.off, q.off};
+  if (q.full) {  // rne(t) + (zp + 128) is an exact integer; the conversion saturates it to [0, 255] = clamp to int8 + 128
+    v2f r0 = (v2f){__builtin_rintf(t0.x), __builtin_rintf(t0.y)} + off;
+    v2f r1 = (v2f){__builtin_rintf(t1.x), __builtin_rintf(t1.y)} + off;
+    return pack4_u8f(r0.x, r0.y, r1.x, r1.y);
+  }
   v2f r0 = {__builtin_amdgcn_fmed3f(__builtin_rintf(t0.x), q.lo_f, q.hi_f), __builtin_amdgcn_fmed3f(__builtin_rintf(t0.y), q.lo_f, q.hi_f)};
   v2f r1 = {__builtin_amdgcn_fmed3f(__builtin_rintf(t1.x), q.lo_f, q.hi_f), __builtin_amdgcn_fmed3f(__builtin_rintf(t1.y), q.lo_f, q.hi_f)};
-  const v2f off = {q.off, q.off};
   r0 = r0 + off;
   r1 = r1 + off;
   return pack4_u8f(r0.x, r0.y, r1.x, r1.y);
@@ -2005,6 +2013,14 @@ static void autotune(vbt_model* m) {
     int bi = 0;
     for (size_t i = 1; i < g.alts.size(); i++)
       if (g.alts[i].ms < g.alts[bi].ms) bi = (int)i;
+    if (const char* pe = getenv("VBT_PREFER_IMAGE")) {  // experiment: whole-image kernel on maps of at most this many pixels
+      for (size_t i = 0; i < g.alts.size(); i++)
+        if (g.alts[i].steps.size() == 1 && g.alts[i].steps[0].family == F_MBCONV && image_geom(m, g.alts[i].steps[0]).ok &&
+            g.alts[i].steps[0].fa.H * g.alts[i].steps[0].fa.W <= atoi(pe)) {
+          bi = (int)i;
+          g.alts[i].steps[0].variant = 5;
+        }
+    }
     g.chosen = bi;
     if (getenv("VBT_AUTOTUNE_VERBOSE")) {
       const Step& f = g.alts[0].steps[0];
