@@ -1893,7 +1893,11 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       }
 #define FB_LAUNCH(KK, S, NBP)                                                                              \
   do {                                                                                                     \
-    if (ex && mdw) fused_block_kernel<KK, S, NBP, true, true><<<grid, 256, lds_bytes, st>>>(a);           \
+    if (ex && mdw && a.KSe == 1) fused_block_kernel<KK, S, NBP, true, true, 1><<<grid, 256, lds_bytes, st>>>(a);      \
+    else if (ex && mdw && a.KSe == 2) fused_block_kernel<KK, S, NBP, true, true, 2><<<grid, 256, lds_bytes, st>>>(a); \
+    else if (ex && mdw && a.KSe == 3) fused_block_kernel<KK, S, NBP, true, true, 3><<<grid, 256, lds_bytes, st>>>(a); \
+    else if (ex && mdw && a.KSe == 4) fused_block_kernel<KK, S, NBP, true, true, 4><<<grid, 256, lds_bytes, st>>>(a); \
+    else if (ex && mdw) fused_block_kernel<KK, S, NBP, true, true><<<grid, 256, lds_bytes, st>>>(a);      \
     else if (ex) fused_block_kernel<KK, S, NBP, true, false><<<grid, 256, lds_bytes, st>>>(a);            \
     else if (mdw) fused_block_kernel<KK, S, NBP, false, true><<<grid, 256, lds_bytes, st>>>(a);           \
     else fused_block_kernel<KK, S, NBP, false, false><<<grid, 256, lds_bytes, st>>>(a);                   \

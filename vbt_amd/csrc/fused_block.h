@@ -63,7 +63,9 @@ struct FusedArgs {
 constexpr int FB_EST = 80;  // E tile bytes per pixel (64 + 16: bank spread, 16-B aligned)
 constexpr int FB_DST = 72;  // D tile bytes per pixel
 
-template <int KK, int S, int NBP, bool EXPAND, bool MDW>
+// KSE > 0: the expand has exactly KSE K-steps and its weights stay in registers for the whole chunk (the pixel-group
+// loop then issues no global loads); KSE == 0: K-steps are a runtime loop that streams the weights.
+template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0>
 __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, unsigned char* fb_smem) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int tx = tile % a.tiles_x;
@@ -204,6 +206,14 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
         em[t] = *(const float4*)(a.me + c * 64 + 16 * g + 4 * t);
       }
       const unsigned zeb = (unsigned)(a.ze & 255) * 0x01010101u;
+      const long* w = a.we + (long)c * a.KSe * 4 * 64 + lane;
+      long wreg[KSE > 0 ? KSE : 1][4];
+      if constexpr (KSE > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KSE; ks++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) wreg[ks][t] = w[(ks * 4 + t) * 64];
+      }
       for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
         const int p = pg * 16 + r;
         const int pc = min(p, NPh - 1);
@@ -211,12 +221,20 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 #pragma unroll
         for (int t = 0; t < 4; t++) ea[t] = v4i_from(eb[t]);
         const unsigned char* brow = T0 + pc * a.T0S + 8 * g;
-        const long* w = a.we + (long)c * a.KSe * 4 * 64 + lane;
-#pragma unroll 2
-        for (int ks = 0; ks < a.KSe; ks++) {
-          long bv = *(const long*)(brow + 32 * ks);
+        if constexpr (KSE > 0) {
 #pragma unroll
-          for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[(ks * 4 + t) * 64], bv, ea[t], 0, 0, 0);
+          for (int ks = 0; ks < KSE; ks++) {
+            long bv = *(const long*)(brow + 32 * ks);
+#pragma unroll
+            for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[ks][t], bv, ea[t], 0, 0, 0);
+          }
+        } else {
+#pragma unroll 2
+          for (int ks = 0; ks < a.KSe; ks++) {
+            long bv = *(const long*)(brow + 32 * ks);
+#pragma unroll
+            for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[(ks * 4 + t) * 64], bv, ea[t], 0, 0, 0);
+          }
         }
         unsigned d[4];
 #pragma unroll
@@ -364,10 +382,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 }
 
 
-template <int KK, int S, int NBP, bool EXPAND, bool MDW>
+template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0>
 __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem_dyn[];
-  fused_block_body<KK, S, NBP, EXPAND, MDW>(a, blockIdx.x, fb_smem_dyn);
+  fused_block_body<KK, S, NBP, EXPAND, MDW, KSE>(a, blockIdx.x, fb_smem_dyn);
 }
 
 // Several independent problems (e.g. the same head layer on all 5 pyramid levels of both heads) in ONE grid:
