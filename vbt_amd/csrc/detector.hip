@@ -75,9 +75,15 @@ __device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, 
   v2f t0 = (v2f){(float)acc[0], (float)acc[1]} * (v2f){mu.x, mu.y};
   v2f t1 = (v2f){(float)acc[2], (float)acc[3]} * (v2f){mu.z, mu.w};
   const v2f off = {q.off, q.off};
-  if (q.full) {  // rne(t) + (zp + 128) is an exact integer; the conversion saturates it to [0, 255] = clamp to int8 + 128
-    v2f r0 = (v2f){__builtin_rintf(t0.x), __builtin_rintf(t0.y)} + off;
-    v2f r1 = (v2f){__builtin_rintf(t1.x), __builtin_rintf(t1.y)} + off;
+  if (q.full) {
+    // rne(t) by the float adder: t + 1.5*2^23 has ulp 1 and an even base, so the sum is exactly 1.5*2^23 + rne(t) for
+    // |t| < 2^22; adding (zp + 128 - 1.5*2^23) is exact again and the u8 conversion saturates to [0, 255], which IS the
+    // clamp to int8 (+128).  |t| >= 2^22 stays far outside [0, 255] on the same side, i.e. saturates like the clamp.
+    // Two packed adds replace four v_rndne + one packed add.
+    const v2f magic = {12582912.0f, 12582912.0f};
+    const v2f back = {q.off - 12582912.0f, q.off - 12582912.0f};
+    v2f r0 = (t0 + magic) + back;
+    v2f r1 = (t1 + magic) + back;
     return pack4_u8f(r0.x, r0.y, r1.x, r1.y);
   }
   v2f r0 = {__builtin_amdgcn_fmed3f(__builtin_rintf(t0.x), q.lo_f, q.hi_f), __builtin_amdgcn_fmed3f(__builtin_rintf(t0.y), q.lo_f, q.hi_f)};
