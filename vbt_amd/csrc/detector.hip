@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <set>
 #include <tuple>
 
 #include "common.h"
@@ -139,6 +140,7 @@ __device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_
 #include "fused_block.h"  // (inside namespace vbt)
 #include "stem_block.h"
 #include "image_block.h"
+#include "node_chain.h"
 
 // ------------------------------------------------------------------------------------------
 // pointwise conv, variant A: K <= 256, activations of 16*MS pixels stay in registers while the
@@ -797,10 +799,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_CHAIN, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
                                            "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node", "fused_heads_multi",
-                                           "fused_stem_block"};
+                                           "fused_stem_block", "fused_bifpn_chain"};
 
 struct Step {
   int op;       // index into ops
@@ -1333,6 +1335,7 @@ static int make_stem_block(vbt_model* m, int si, Step* out) {
   return VBT_OK;
 }
 
+static int chain_nodes(vbt_model* m);
 static int fuse_plan(vbt_model* m) {
   const int no = (int)m->ops.size();
   std::vector<int> consumers(m->tensors.size(), 0);
@@ -1508,6 +1511,92 @@ static int fuse_plan(vbt_model* m) {
     int rc = batch_heads(m);
     if (rc) return rc;
   }
+  if (fuse_node) return chain_nodes(m);
+  return VBT_OK;
+}
+
+// Consecutive small BiFPN nodes -> one launch (node_chain.h).  Groups that sit between two chain members but do not
+// depend on the chain (the lateral 1x1 convs of the first cell) are hoisted in front of it.
+static int chain_nodes(vbt_model* m) {
+  if (!(m->flags & VBT_MODEL_NODE_CHAIN)) return VBT_OK;  // opt-in: measured slower than one launch per node at B = 64
+  auto small_node = [&](const Group& g) {
+    const Alt& fa = g.alts.back();
+    if (fa.steps.size() != 1 || fa.steps[0].family != F_NODE) return false;
+    const Step& st = fa.steps[0];
+    const OpRec& d = m->ops[st.d_op];
+    const int HW = st.fa.H * st.fa.W, NB = (st.fa.Cout + 63) / 64;
+    return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= 400 &&
+           ((HW + 15) / 16) * NB <= NC_WAVES * NC_MAXU && st.fa.Cin % 4 == 0;
+  };
+  auto outputs_of = [&](const Group& g, std::set<int>& acc) {
+    for (const Step& st : g.alts[0].steps) acc.insert(m->ops[st.op].output);
+  };
+  auto depends_on = [&](const Group& g, const std::set<int>& produced) {
+    for (const Step& st : g.alts[0].steps) {
+      const OpRec& op = m->ops[st.op];
+      for (int i = 0; i < op.n_inputs; i++)
+        if (produced.count(op.inputs[i])) return true;
+    }
+    return false;
+  };
+  std::vector<Group> out;
+  const size_t n = m->groups.size();
+  for (size_t i = 0; i < n;) {
+    if (!small_node(m->groups[i])) { out.push_back(m->groups[i]); i++; continue; }
+    std::vector<size_t> chain{i}, hoisted;
+    std::set<int> produced;
+    outputs_of(m->groups[i], produced);
+    size_t j = i + 1;
+    while (j < n) {
+      if (small_node(m->groups[j])) { chain.push_back(j); outputs_of(m->groups[j], produced); j++; continue; }
+      size_t k = j;  // a run of independent groups followed by another small node?
+      while (k < n && !small_node(m->groups[k]) && !depends_on(m->groups[k], produced)) k++;
+      if (k < n && k > j && small_node(m->groups[k])) {
+        for (size_t h = j; h < k; h++) hoisted.push_back(h);
+        j = k;
+        continue;
+      }
+      break;
+    }
+    for (size_t h : hoisted) out.push_back(m->groups[h]);
+    if (chain.size() < 2) {
+      out.push_back(m->groups[chain[0]]);
+    } else {
+      Group g;
+      Alt each, ch;
+      Step cs;
+      cs.family = F_CHAIN;
+      std::vector<FusedArgs> hargs;
+      for (size_t ci : chain) {
+        const Alt& fa = m->groups[ci].alts.back();
+        const Step& ns = fa.steps[0];
+        each.steps.push_back(ns);
+        for (int t : fa.hidden) { each.hidden.push_back(t); ch.hidden.push_back(t); }
+        cs.members.push_back(ns);
+        cs.op = ns.op;
+        cs.d_op = ns.d_op;
+        cs.alg_bytes_per_frame += ns.alg_bytes_per_frame;
+        cs.weight_bytes += ns.weight_bytes;
+        cs.macs_per_frame += ns.macs_per_frame;
+        FusedArgs a = ns.fa;
+        for (int q = 0; q < 3; q++) a.src[q] = ns.src_tensor[q] >= 0 ? m->tptr[ns.src_tensor[q]] : nullptr;
+        a.x = nullptr;
+        a.out = m->tptr[m->ops[ns.op].output];
+        hargs.push_back(a);
+        const int Cp = a.nchunks * 64, HW = a.H * a.W;
+        cs.lds_bytes = std::max(cs.lds_bytes, (a.H + 2) * (a.W + 2) * (Cp + 16) + ((HW + 15) / 16) * 16 * FB_DST);
+      }
+      int rc = upload(m, hargs, &cs.d_multi);
+      if (rc) return rc;
+      ch.steps.push_back(cs);
+      g.alts.push_back(each);
+      g.alts.push_back(ch);
+      g.chosen = 1;
+      out.push_back(g);
+    }
+    i = j;
+  }
+  m->groups.swap(out);
   return VBT_OK;
 }
 
@@ -1923,6 +2012,23 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       else FB_NBP(5, 2);
 #undef FB_NBP
 #undef FB_LAUNCH
+      break;
+    }
+    case F_CHAIN: {
+      if (boff != 0) {  // sub-batches on side streams: the chain's pointers are those of the whole batch
+        for (const Step& ms : s.members) {
+          int rc = launch_step(m, ms, B, st, frames - (size_t)boff * m->hdr.image_size * m->hdr.image_size * 3, boxes - (size_t)boff * m->hdr.max_detections * 4,
+                               scores - (size_t)boff * m->hdr.max_detections, classes - (size_t)boff * m->hdr.max_detections, counts - boff, boff);
+          if (rc) return rc;
+        }
+        break;
+      }
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+      }
+      node_chain_kernel<<<dim3((unsigned)B), NC_THREADS, s.lds_bytes, st>>>(s.d_multi, (int)s.members.size());
       break;
     }
     case F_STEMBLK: {

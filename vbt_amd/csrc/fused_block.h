@@ -261,20 +261,24 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       const float4 mum = *(const float4*)(a.md + c * 64 + 16 * wave + 4 * g);
       const unsigned char* lane_base = Ein + 16 * wave + 8 * (g & 1);
       const int hi_half = g >> 1;
+      // two slot groups at a time: their MFMA chains are independent, so one hides the other's accumulate latency
 #pragma unroll
-      for (int pg = 0; pg < 4; pg++) {
-        v4i dq = v4i_from(bqm);
-        const unsigned char* pb = lane_base + hbase[pg] * est;
+      for (int pg = 0; pg < 4; pg += 2) {
+        v4i dqa = v4i_from(bqm), dqb = v4i_from(bqm);
+        const unsigned char* pba = lane_base + hbase[pg] * est;
+        const unsigned char* pbb = lane_base + hbase[pg + 1] * est;
 #pragma unroll
         for (int mi = 0; mi < KT; mi++) {
-          constexpr int dummy = 0;
-          (void)dummy;
           const int ta = 2 * mi, tb = (2 * mi + 1 < KK * KK) ? 2 * mi + 1 : 2 * mi;  // odd tap count: the pad tap has zero weights
           const int offa = ((ta / KK) * HWx + (ta % KK)) * est, offb = ((tb / KK) * HWx + (tb % KK)) * est;
-          long bv = *(const long*)(pb + (hi_half ? offb : offa));
-          dq = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bv, dq, 0, 0, 0);
+          const int off = hi_half ? offb : offa;
+          long bva = *(const long*)(pba + off);
+          long bvb = *(const long*)(pbb + off);
+          dqa = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bva, dqa, 0, 0, 0);
+          dqb = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bvb, dqb, 0, 0, 0);
         }
-        *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dq, mum, a.rqd);
+        *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dqa, mum, a.rqd);
+        *(unsigned*)(D + ((pg + 1) * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dqb, mum, a.rqd);
       }
     } else if (dw_active) {
       const unsigned char* Ein = EXPAND ? E + 4 * cq : T0 + 64 * c + 4 * cq;
