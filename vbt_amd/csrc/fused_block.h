@@ -193,6 +193,19 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       hbase[pg] = (py_ * S) * HWx + px_ * S;
     }
   }
+  // SeparableConv / node / head tiles (no expand): the first chunk's depthwise operands do not depend on the tile, so
+  // they are requested before the barrier and their latency overlaps the input tile loads
+  constexpr int KTP = (KK * KK + 1) / 2;
+  long wpre[KTP];
+  int4 bpre = make_int4(0, 0, 0, 0);
+  float4 mpre = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (!EXPAND && MDW) {
+    const long* wm0 = a.wdm + ((long)wave * KTP) * 64 + lane;
+#pragma unroll
+    for (int mi = 0; mi < KTP; mi++) wpre[mi] = wm0[mi * 64];
+    bpre = *(const int4*)(a.bdm + 16 * wave + 4 * g);
+    mpre = *(const float4*)(a.md + 16 * wave + 4 * g);
+  }
   __syncthreads();
 
   for (int c = 0; c < a.nchunks; c++) {
@@ -255,10 +268,19 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       const int est = EXPAND ? FB_EST : a.T0S;
       const long* wm = a.wdm + ((long)(c * 4 + wave) * KT) * 64 + lane;
       long wreg[KT];
+      int4 bqm;
+      float4 mum;
+      if (!EXPAND && c == 0) {
 #pragma unroll
-      for (int mi = 0; mi < KT; mi++) wreg[mi] = wm[mi * 64];
-      const int4 bqm = *(const int4*)(a.bdm + c * 64 + 16 * wave + 4 * g);
-      const float4 mum = *(const float4*)(a.md + c * 64 + 16 * wave + 4 * g);
+        for (int mi = 0; mi < KT; mi++) wreg[mi] = wpre[mi];
+        bqm = bpre;
+        mum = mpre;
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < KT; mi++) wreg[mi] = wm[mi * 64];
+        bqm = *(const int4*)(a.bdm + c * 64 + 16 * wave + 4 * g);
+        mum = *(const float4*)(a.md + c * 64 + 16 * wave + 4 * g);
+      }
       const unsigned char* lane_base = Ein + 16 * wave + 8 * (g & 1);
       const int hi_half = g >> 1;
       // two slot groups at a time: their MFMA chains are independent, so one hides the other's accumulate latency
