@@ -209,6 +209,17 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   __syncthreads();
 
   for (int c = 0; c < a.nchunks; c++) {
+    // low-resolution blocks (KSE >= 3 <=> Cin >= 80: few workgroups, latency-bound): this chunk's depthwise operands are
+    // requested now and consumed after the expand stage.  On the high-resolution blocks the extra live registers cost
+    // more than the hidden latency gains (b1: 100 -> 114 us), so they keep loading after the barrier.
+    constexpr bool PREF_DW = EXPAND && MDW && KSE >= 3;
+    if constexpr (PREF_DW) {
+      const long* wmc = a.wdm + ((long)(c * 4 + wave) * KTP) * 64 + lane;
+#pragma unroll
+      for (int mi = 0; mi < KTP; mi++) wpre[mi] = wmc[mi * 64];
+      bpre = *(const int4*)(a.bdm + c * 64 + 16 * wave + 4 * g);
+      mpre = *(const float4*)(a.md + c * 64 + 16 * wave + 4 * g);
+    }
     if (EXPAND) {
       // ---- stage E: expand chunk c on every halo pixel ----
       int4 eb[4];
@@ -270,7 +281,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       long wreg[KT];
       int4 bqm;
       float4 mum;
-      if (!EXPAND && c == 0) {
+      if (PREF_DW || (!EXPAND && c == 0)) {
 #pragma unroll
         for (int mi = 0; mi < KT; mi++) wreg[mi] = wpre[mi];
         bqm = bpre;
