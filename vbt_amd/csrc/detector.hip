@@ -18,6 +18,7 @@
 #include <cmath>
 #include <map>
 #include <set>
+#include <type_traits>
 #include <tuple>
 
 #include "common.h"
@@ -72,11 +73,12 @@ __device__ __forceinline__ unsigned pack4_u8f(float a, float b, float c, float d
 // acc already contains the bias (accumulators are initialised with it).  The multiply and the offset add use the
 // packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32: two IEEE single ops per instruction, same results).
 typedef float v2f __attribute__((ext_vector_type(2)));
+template <int FULLK = -1>
 __device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, const Rq& q) {
   v2f t0 = (v2f){(float)acc[0], (float)acc[1]} * (v2f){mu.x, mu.y};
   v2f t1 = (v2f){(float)acc[2], (float)acc[3]} * (v2f){mu.z, mu.w};
   const v2f off = {q.off, q.off};
-  if (q.full) {
+  if (FULLK == 1 || (FULLK < 0 && q.full)) {
     // rne(t) by the float adder: t + 1.5*2^23 has ulp 1 and an even base, so the sum is exactly 1.5*2^23 + rne(t) for
     // |t| < 2^22; adding (zp + 128 - 1.5*2^23) is exact again and the u8 conversion saturates to [0, 255], which IS the
     // clamp to int8 (+128).  |t| >= 2^22 stays far outside [0, 255] on the same side, i.e. saturates like the clamp.
@@ -2035,7 +2037,8 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       StemBlockArgs a = s.sb;
       a.frames = frames;
       a.out = out;
-      stem_block_kernel<<<dim3((unsigned)((long)B * a.tiles_x * a.tiles_y)), 256, 0, st>>>(a);
+      if (a.rqs.full && a.rqd.full && a.rqp.full) stem_block_kernel<true><<<dim3((unsigned)((long)B * a.tiles_x * a.tiles_y)), 256, 0, st>>>(a);
+      else stem_block_kernel<false><<<dim3((unsigned)((long)B * a.tiles_x * a.tiles_y)), 256, 0, st>>>(a);
       break;
     }
     case F_POST: {

@@ -238,35 +238,42 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 #pragma unroll
           for (int t = 0; t < 4; t++) wreg[ks][t] = w[(ks * 4 + t) * 64];
       }
-      for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
-        const int p = pg * 16 + r;
-        const int pc = min(p, NPh - 1);
-        v4i ea[4];
+      // the requantisation flavour (saturating / explicitly clamped) is uniform: pick it once, outside the loop, so the
+      // loop body stays one basic block and the scheduler can overlap the four MFMAs with the previous tile's epilogue
+      auto expand_loop = [&](auto full_tag) {
+        constexpr int FULLK = decltype(full_tag)::value;
+        for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
+          const int p = pg * 16 + r;
+          const int pc = min(p, NPh - 1);
+          v4i ea[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) ea[t] = v4i_from(eb[t]);
-        const unsigned char* brow = T0 + pc * a.T0S + 8 * g;
-        if constexpr (KSE > 0) {
+          for (int t = 0; t < 4; t++) ea[t] = v4i_from(eb[t]);
+          const unsigned char* brow = T0 + pc * a.T0S + 8 * g;
+          if constexpr (KSE > 0) {
 #pragma unroll
-          for (int ks = 0; ks < KSE; ks++) {
-            long bv = *(const long*)(brow + 32 * ks);
+            for (int ks = 0; ks < KSE; ks++) {
+              long bv = *(const long*)(brow + 32 * ks);
 #pragma unroll
-            for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[ks][t], bv, ea[t], 0, 0, 0);
-          }
-        } else {
+              for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[ks][t], bv, ea[t], 0, 0, 0);
+            }
+          } else {
 #pragma unroll 2
-          for (int ks = 0; ks < a.KSe; ks++) {
-            long bv = *(const long*)(brow + 32 * ks);
+            for (int ks = 0; ks < a.KSe; ks++) {
+              long bv = *(const long*)(brow + 32 * ks);
 #pragma unroll
-            for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[(ks * 4 + t) * 64], bv, ea[t], 0, 0, 0);
+              for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[(ks * 4 + t) * 64], bv, ea[t], 0, 0, 0);
+            }
           }
-        }
-        unsigned d[4];
+          unsigned d[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-          d[t] = rq_pack_b(ea[t], em[t], a.rqe);
-        if ((oob_mask >> i) & 1u) { d[0] = zeb; d[1] = zeb; d[2] = zeb; d[3] = zeb; }
-        if (!((tail_mask >> i) & 1u)) *(uint4*)(E + p * FB_EST + 16 * g) = make_uint4(d[0], d[1], d[2], d[3]);
-      }
+          for (int t = 0; t < 4; t++)
+            d[t] = rq_pack_b<FULLK>(ea[t], em[t], a.rqe);
+          if ((oob_mask >> i) & 1u) { d[0] = zeb; d[1] = zeb; d[2] = zeb; d[3] = zeb; }
+          if (!((tail_mask >> i) & 1u)) *(uint4*)(E + p * FB_EST + 16 * g) = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+      };
+      if (a.rqe.full) expand_loop(std::integral_constant<int, 1>{});
+      else expand_loop(std::integral_constant<int, 0>{});
       __syncthreads();
     }
     // ---- stage D: depthwise on chunk c ----

@@ -39,7 +39,10 @@ struct StemBlockArgs {
 constexpr int SB_HW = 18, SB_NPH = SB_HW * SB_HW, SB_NPG = (SB_NPH + 15) / 16;
 constexpr int SB_RROWS = 37, SB_RDW = 30, SB_RST = SB_RDW * 4, SB_PST = 32, SB_SST = 40, SB_DST = 40;
 
+// FULL: all three requantisations clamp at the int8 limits (the saturating flavour, no per-element branch)
+template <bool FULL>
 __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
+  constexpr int FK = FULL ? 1 : -1;
   // R is dead once P is built and P once S is built: R shares S's storage, D shares P's (23.8 KB -> 6 workgroups / CU)
   __shared__ __attribute__((aligned(16))) unsigned char SR[SB_NPH * SB_SST + 64];
   __shared__ __attribute__((aligned(16))) unsigned char PD[SB_NPG * 16 * SB_PST];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
       v4i a0 = v4i_from(b0), a1 = v4i_from(b1);
       a0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(wa0, bv, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(wa1, bv, a1, 0, 0, 0);
-      unsigned q0 = rq_pack_b(a0, m0, a.rqs), q1 = rq_pack_b(a1, m1, a.rqs);
+      unsigned q0 = rq_pack_b<FK>(a0, m0, a.rqs), q1 = rq_pack_b<FK>(a1, m1, a.rqs);
       const int hy = pc / SB_HW, hx = pc - hy * SB_HW;
       const int sy = sy0 + hy, sx = sx0 + hx;
       if (!(sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW)) { q0 = a.zs4; q1 = a.zs4; }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
         const long bv = *(const long*)(pb + (hi_half ? offb : offa));
         dq = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bv, dq, 0, 0, 0);
       }
-      *(unsigned*)(D + (py * 16 + r) * SB_DST + 16 * cg + 4 * g) = rq_pack_b(dq, mum, a.rqd);
+      *(unsigned*)(D + (py * 16 + r) * SB_DST + 16 * cg + 4 * g) = rq_pack_b<FK>(dq, mum, a.rqd);
     }
   }
   __syncthreads();
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
       const long bv = *(const long*)(D + (py * 16 + r) * SB_DST + 8 * g);
       v4i acc = v4i_from(bb);
       acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(wa, bv, acc, 0, 0, 0);
-      const unsigned q = rq_pack_b(acc, mm, a.rqp);
+      const unsigned q = rq_pack_b<FK>(acc, mm, a.rqp);
       const int oy = oy0 + py, ox = ox0 + r;
       if (oy < a.SH && ox < a.SW && 4 * g < a.Cout) *(unsigned*)(a.out + ((b * a.SH + oy) * (long)a.SW + ox) * a.Cout + 4 * g) = q;
     }
