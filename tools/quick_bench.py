@@ -8,10 +8,11 @@ from vbt_amd.interpreter import Interpreter
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-model = os.path.join(os.path.dirname(__file__), "..", "models", "efficientdet_lite0_synth.vbtm")
+model = os.environ.get("VBT_MODEL", os.path.join(os.path.dirname(__file__), "..", "models", "efficientdet_lite0_synth.vbtm"))
 it = Interpreter(model, max_batch=B)
 print('launches per forward:', it.num_launches())
-frames = np.stack([synth.render(synth.background(s), 3 * s) for s in range(min(B, 16))])
+size = int(it.get_input_details()[0]["shape"][1])
+frames = np.stack([synth.render(synth.background(s, size), 3 * s) for s in range(min(B, 16))])
 frames = np.concatenate([frames] * ((B + len(frames) - 1) // len(frames)))[:B]
 dev = torch.device("cuda:0")
 fd = torch.from_numpy(frames).to(dev)

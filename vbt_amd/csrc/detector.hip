@@ -1175,7 +1175,7 @@ static int batch_heads(vbt_model* m) {
   auto mergeable = [&](const std::vector<int>& mem) {
     if (mem.size() < 2 || mem.size() > 12) return false;
     const Step& s0 = m->groups[mem[0]].alts.back().steps[0];
-    if (!(s0.nbp == 1 && m->ops[s0.d_op].k == 3 && m->ops[s0.d_op].stride == 1)) return false;  // the instantiation built below
+    if (!((s0.nbp == 1 || s0.nbp == 2) && m->ops[s0.d_op].k == 3 && m->ops[s0.d_op].stride == 1)) return false;  // the instantiations built below
     for (int gi : mem) {
       const Step& st = m->groups[gi].alts.back().steps[0];
       if (st.nbp != s0.nbp || m->ops[st.d_op].k != 3 || m->ops[st.d_op].stride != 1) return false;
@@ -1943,6 +1943,9 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       if (dop.k == 3 && dop.stride == 1 && s.nbp == 1) {
         if (mdw) fused_block_multi_kernel<3, 1, 1, false, true><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
         else fused_block_multi_kernel<3, 1, 1, false, false><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
+      } else if (dop.k == 3 && dop.stride == 1 && s.nbp == 2) {  // BiFPN width 65..128 (Lite1 / Lite2)
+        if (mdw) fused_block_multi_kernel<3, 1, 2, false, true><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
+        else fused_block_multi_kernel<3, 1, 2, false, false><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
       } else {
         set_error("fused_heads_multi: unsupported instantiation (k=%d s=%d nbp=%d)", dop.k, dop.stride, s.nbp);
         return VBT_ERR_ARG;
