@@ -16,6 +16,7 @@
 //     candidates in LDS -> greedy suppression by one wavefront with ballot/shuffle.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <map>
 #include <set>
 #include <type_traits>
@@ -2072,19 +2073,44 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
   return VBT_OK;
 }
 
+// VBT_AUTOTUNE_CONCURRENCY=n (default 1): time each candidate with n copies in flight on n streams (same buffers, same
+// results) and rank by time per copy, i.e. by throughput under contention - what a pipelined caller (Pipeline depth n)
+// experiences - instead of by isolated latency.
 static double time_step(vbt_model* m, const Step& s, int B, int reps) {
+  static int nconc = -1;
+  static hipStream_t cs[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (nconc < 0) {
+    const char* e = getenv("VBT_AUTOTUNE_CONCURRENCY");
+    nconc = e ? std::max(1, std::min(4, atoi(e))) : 1;
+    if (nconc > 1)
+      for (int i = 0; i < nconc; i++) (void)hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking);
+  }
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1e30;
-  launch_step(m, s, B, nullptr, m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
-  (void)hipEventRecord(e0, nullptr);
-  for (int r = 0; r < reps; r++)
-    launch_step(m, s, B, nullptr, m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
-  (void)hipEventRecord(e1, nullptr);
   float ms = 1e30f;
-  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
+  if (nconc <= 1) {
+    launch_step(m, s, B, nullptr, m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+    (void)hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps; r++)
+      launch_step(m, s, B, nullptr, m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) ms = 1e30f;
+    ms /= reps;
+  } else {
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < nconc; i++)
+      launch_step(m, s, B, cs[i], m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+    (void)hipDeviceSynchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; r++)
+      for (int i = 0; i < nconc; i++)
+        launch_step(m, s, B, cs[i], m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+    (void)hipDeviceSynchronize();
+    ms = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (reps * nconc));
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  return ms / reps;
+  return ms;
 }
 
 // Plan-time autotuning: every alternative computes bit-identical tensors, so only speed is at stake.
