@@ -24,7 +24,7 @@ def oracle_run(oracle_lib, model_path, frames):
 # plan flags (include/vbt_hip.h): 1 = one kernel per graph op; 8 = no autotuning -> the most fused alternative of
 # every group (incl. whole BiFPN nodes); 8|2 = dw+project fused, expand separate; 8|16 = no BiFPN node fusion;
 # 0 = autotuned mix (whatever is fastest on this GPU)
-@pytest.mark.parametrize("flags", [1, 8, 8 | 2, 8 | 16, 8 | 128, 8 | 256, 8 | 512, 8 | 1024, 0])
+@pytest.mark.parametrize("flags", [1, 8, 8 | 2, 8 | 16, 8 | 128, 8 | 256, 8 | 512, 8 | 1024, 8 | 2048, 0])
 def test_every_tensor_bit_exact(model_path, frames, oracle_run, flags):
     """Every plan must reproduce the oracle bit for bit: all 241 tensors when unfused, every tensor that still
     reaches HBM otherwise (fused MBConv / SeparableConv blocks keep their intermediates in LDS)."""

@@ -1092,6 +1092,43 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
       s.weight_bytes += m->op_steps[oi].weight_bytes;
       s.macs_per_frame += m->op_steps[oi].macs_per_frame;
     }
+  if (expand && Ce % 48 == 0 && Ce % 64 != 0) {
+    // 48-channel chunking of the same block (fused_block.h, template NT = 3): no padded channels
+    const OpRec& eop = m->ops[e_op];
+    const int8_t* we = (const int8_t*)(m->blob.data() + eop.w_off);
+    const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
+    const int8_t* wpj = (const int8_t*)(m->blob.data() + pop.w_off);
+    const int K = tin.c, KSe = a.KSe, nch3 = Ce / 48, KT = (kk + 1) / 2;
+    std::vector<long> we3((size_t)nch3 * KSe * 3 * 64, 0), wdm3((size_t)nch3 * 3 * KT * 64, 0), wp3;
+    int8_t* o = (int8_t*)we3.data();
+    for (int c = 0; c < nch3; c++)
+      for (int ks = 0; ks < KSe; ks++)
+        for (int t = 0; t < 3; t++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int i = lane & 15, kg = lane >> 4, co = 48 * c + 12 * (i >> 2) + 4 * t + (i & 3);
+            for (int j = 0; j < 8; j++) {
+              const int k = 32 * ks + 8 * kg + j;
+              o[((((size_t)(c * KSe + ks) * 3 + t) * 64 + lane) * 8) + j] = k < K ? we[(size_t)co * K + k] : 0;
+            }
+          }
+    int8_t* od = (int8_t*)wdm3.data();
+    for (int c = 0; c < nch3; c++)
+      for (int cg = 0; cg < 3; cg++)
+        for (int mi = 0; mi < KT; mi++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int i = lane & 15, g = lane >> 4, ch = 48 * c + 16 * cg + i, tap = 2 * mi + (g >> 1);
+            for (int j = 0; j < 8; j++)
+              od[((((size_t)(c * 3 + cg) * KT + mi) * 64 + lane) * 8) + j] = (tap < kk && 8 * (g & 1) + j == i) ? wd[(size_t)tap * Ce + ch] : 0;
+          }
+    std::vector<int> kmap((size_t)nch3 * 64, -1);
+    for (int c = 0; c < nch3; c++)
+      for (int q = 0; q < 48; q++) kmap[(size_t)c * 64 + q] = 48 * c + q;
+    pack_weights(wpj, tout.c, Ce, 2 * nch3, ps.NB <= 3 ? ps.NB : 5, &kmap, wp3);
+    long *d1, *d2, *d3;
+    int rc;
+    if ((rc = upload(m, we3, &d1)) || (rc = upload(m, wdm3, &d2)) || (rc = upload(m, wp3, &d3))) return rc;
+    a.we3 = d1; a.wdm3 = d2; a.wp3 = d3; a.nch3 = nch3; a.KSp3 = 2 * nch3;
+  }
   if (expand && tin.h * tin.w <= 400 && tout.h * tout.w <= 400) {
     // whole-image kernel (image_block.h): one contiguous record per 64-channel chunk
     const OpRec& eop = m->ops[e_op];
@@ -1965,8 +2002,9 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const bool ex = s.family == F_MBCONV;
       // (the tile option of the variant is applied below, before the launch macros use `grid` / `lds_bytes`)
       // variant bit 0: depthwise on the matrix pipe (default) / VALU; bits 1..: 0 = heuristic tile, 1 = half-height tile
-      const int var = s.variant < 0 ? (((m->flags & VBT_MODEL_IMAGE_BLOCKS) && image_geom(m, s).ok) ? 5 : 1) : s.variant;
+      const int var = s.variant < 0 ? (((m->flags & VBT_MODEL_IMAGE_BLOCKS) && image_geom(m, s).ok) ? 5 : ((m->flags & VBT_MODEL_CHUNK48) ? 9 : 1)) : s.variant;
       const bool mdw = var & 1;
+      const bool nt3 = (var & 8) && mdw && a.nch3 > 0 && s.nbp <= 2 && a.KSe >= 1 && a.KSe <= 4;  // 48-channel chunks
       if (var & 4) {  // one workgroup per image (low-resolution blocks)
         const ImageGeom ig = image_geom(m, s);
         if (!ig.ok) { set_error("fused_mbconv: whole-image variant not applicable"); return VBT_ERR_ARG; }
@@ -1984,7 +2022,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         break;
       }
       int lds_bytes = s.lds_bytes;
-      if ((var >> 1) == 1 && a.TY >= 2) {
+      if (((var >> 1) & 1) == 1 && a.TY >= 2) {
         a.TY = (a.TY + 1) / 2;
         a.tiles_y = (a.OH + a.TY - 1) / a.TY;
         const int TXp_ = (a.TX + 3) & ~3;
@@ -1994,7 +2032,11 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       }
 #define FB_LAUNCH(KK, S, NBP)                                                                              \
   do {                                                                                                     \
-    if (ex && mdw && a.KSe == 1) fused_block_kernel<KK, S, NBP, true, true, 1><<<grid, 256, lds_bytes, st>>>(a);      \
+    if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 3><<<grid, 256, lds_bytes, st>>>(a);      \
+    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 2) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 2, 3><<<grid, 256, lds_bytes, st>>>(a); \
+    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 3) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 3, 3><<<grid, 256, lds_bytes, st>>>(a); \
+    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 4) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 4, 3><<<grid, 256, lds_bytes, st>>>(a); \
+    else if (ex && mdw && a.KSe == 1) fused_block_kernel<KK, S, NBP, true, true, 1><<<grid, 256, lds_bytes, st>>>(a);      \
     else if (ex && mdw && a.KSe == 2) fused_block_kernel<KK, S, NBP, true, true, 2><<<grid, 256, lds_bytes, st>>>(a); \
     else if (ex && mdw && a.KSe == 3) fused_block_kernel<KK, S, NBP, true, true, 3><<<grid, 256, lds_bytes, st>>>(a); \
     else if (ex && mdw && a.KSe == 4) fused_block_kernel<KK, S, NBP, true, true, 4><<<grid, 256, lds_bytes, st>>>(a); \
@@ -2139,6 +2181,7 @@ static void autotune(vbt_model* m) {
         } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
           cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
           if (image_geom(m, st).ok) cand.push_back(5);  // one workgroup per image
+          if (st.family == F_MBCONV && st.fa.nch3 > 0 && st.nbp <= 2 && st.fa.KSe >= 1 && st.fa.KSe <= 4) { cand.push_back(9); cand.push_back(11); }  // 48-channel chunks
         } else if (st.family == F_MULTI) {
           cand = {0, 1};
         }

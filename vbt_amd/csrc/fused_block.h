@@ -31,6 +31,12 @@ struct FusedArgs {
   const float* me;
   int KSe, ze, loe, hie;
   Rq rqe;
+  // 48-channel chunking (template NT = 3) of the same block, for expanded widths that are multiples of 48 but not of 64
+  // (6 x {16, 24, 40, 80, 112}): no padded channels in the expand / depthwise stages.  nch3 == 0: not available.
+  const long* we3;   // [(c*KSe + ks)*3 + t][lane]: cout = 48c + 12(i>>2) + 4t + (i&3)
+  const long* wdm3;  // [(c*3 + cg)*KT + m][lane]: channel 48c + 16cg + i
+  const long* wp3;   // project weights, K-steps 2c, 2c+1 = channels 48c..48c+47 (+16 zero columns)
+  int nch3, KSp3;
   // depthwise
   const float* wd;  // [k*k][Ce_pad]
   const int* bd;    // folded, padded to Ce_pad
@@ -65,7 +71,7 @@ constexpr int FB_DST = 72;  // D tile bytes per pixel
 
 // KSE > 0: the expand has exactly KSE K-steps and its weights stay in registers for the whole chunk (the pixel-group
 // loop then issues no global loads); KSE == 0: K-steps are a runtime loop that streams the weights.
-template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0>
+template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4>
 __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, unsigned char* fb_smem) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int tx = tile % a.tiles_x;
@@ -208,35 +214,41 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   }
   __syncthreads();
 
-  for (int c = 0; c < a.nchunks; c++) {
+  constexpr int CH = 16 * NT;                       // channels per chunk
+  const int nch = NT == 3 ? a.nch3 : a.nchunks;
+  const long* const wdm_ = NT == 3 ? a.wdm3 : a.wdm;
+  for (int c = 0; c < nch; c++) {
     // low-resolution blocks (KSE >= 3 <=> Cin >= 80: few workgroups, latency-bound): this chunk's depthwise operands are
     // requested now and consumed after the expand stage.  On the high-resolution blocks the extra live registers cost
     // more than the hidden latency gains (b1: 100 -> 114 us), so they keep loading after the barrier.
     constexpr bool PREF_DW = EXPAND && MDW && KSE >= 3;
     if constexpr (PREF_DW) {
-      const long* wmc = a.wdm + ((long)(c * 4 + wave) * KTP) * 64 + lane;
+      if (NT == 4 || wave < NT) {
+        const long* wmc = wdm_ + ((long)(c * NT + wave) * KTP) * 64 + lane;
 #pragma unroll
-      for (int mi = 0; mi < KTP; mi++) wpre[mi] = wmc[mi * 64];
-      bpre = *(const int4*)(a.bdm + c * 64 + 16 * wave + 4 * g);
-      mpre = *(const float4*)(a.md + c * 64 + 16 * wave + 4 * g);
+        for (int mi = 0; mi < KTP; mi++) wpre[mi] = wmc[mi * 64];
+        bpre = *(const int4*)(a.bdm + c * CH + 16 * wave + 4 * g);
+        mpre = *(const float4*)(a.md + c * CH + 16 * wave + 4 * g);
+      }
     }
     if (EXPAND) {
       // ---- stage E: expand chunk c on every halo pixel ----
-      int4 eb[4];
-      float4 em[4];
+      // lane (r, g) owns the 4*NT consecutive channels c*CH + 4*NT*g + 4t + j, t < NT
+      int4 eb[NT];
+      float4 em[NT];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        eb[t] = *(const int4*)(a.be + c * 64 + 16 * g + 4 * t);
-        em[t] = *(const float4*)(a.me + c * 64 + 16 * g + 4 * t);
+      for (int t = 0; t < NT; t++) {
+        eb[t] = *(const int4*)(a.be + c * CH + 4 * NT * g + 4 * t);
+        em[t] = *(const float4*)(a.me + c * CH + 4 * NT * g + 4 * t);
       }
       const unsigned zeb = (unsigned)(a.ze & 255) * 0x01010101u;
-      const long* w = a.we + (long)c * a.KSe * 4 * 64 + lane;
-      long wreg[KSE > 0 ? KSE : 1][4];
+      const long* w = (NT == 3 ? a.we3 : a.we) + (long)c * a.KSe * NT * 64 + lane;
+      long wreg[KSE > 0 ? KSE : 1][NT];
       if constexpr (KSE > 0) {
 #pragma unroll
         for (int ks = 0; ks < KSE; ks++)
 #pragma unroll
-          for (int t = 0; t < 4; t++) wreg[ks][t] = w[(ks * 4 + t) * 64];
+          for (int t = 0; t < NT; t++) wreg[ks][t] = w[(ks * NT + t) * 64];
       }
       // the requantisation flavour (saturating / explicitly clamped) is uniform: pick it once, outside the loop, so the
       // loop body stays one basic block and the scheduler can overlap the four MFMAs with the previous tile's epilogue
@@ -245,31 +257,39 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
         for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
           const int p = pg * 16 + r;
           const int pc = min(p, NPh - 1);
-          v4i ea[4];
+          v4i ea[NT];
 #pragma unroll
-          for (int t = 0; t < 4; t++) ea[t] = v4i_from(eb[t]);
+          for (int t = 0; t < NT; t++) ea[t] = v4i_from(eb[t]);
           const unsigned char* brow = T0 + pc * a.T0S + 8 * g;
           if constexpr (KSE > 0) {
 #pragma unroll
             for (int ks = 0; ks < KSE; ks++) {
               long bv = *(const long*)(brow + 32 * ks);
 #pragma unroll
-              for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[ks][t], bv, ea[t], 0, 0, 0);
+              for (int t = 0; t < NT; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[ks][t], bv, ea[t], 0, 0, 0);
             }
           } else {
 #pragma unroll 2
             for (int ks = 0; ks < a.KSe; ks++) {
               long bv = *(const long*)(brow + 32 * ks);
 #pragma unroll
-              for (int t = 0; t < 4; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[(ks * 4 + t) * 64], bv, ea[t], 0, 0, 0);
+              for (int t = 0; t < NT; t++) ea[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[(ks * NT + t) * 64], bv, ea[t], 0, 0, 0);
             }
           }
-          unsigned d[4];
+          unsigned d[NT];
 #pragma unroll
-          for (int t = 0; t < 4; t++)
+          for (int t = 0; t < NT; t++) {
             d[t] = rq_pack_b<FULLK>(ea[t], em[t], a.rqe);
-          if ((oob_mask >> i) & 1u) { d[0] = zeb; d[1] = zeb; d[2] = zeb; d[3] = zeb; }
-          if (!((tail_mask >> i) & 1u)) *(uint4*)(E + p * FB_EST + 16 * g) = make_uint4(d[0], d[1], d[2], d[3]);
+            if ((oob_mask >> i) & 1u) d[t] = zeb;
+          }
+          if (!((tail_mask >> i) & 1u)) {
+            if constexpr (NT == 4) {
+              *(uint4*)(E + p * FB_EST + 16 * g) = make_uint4(d[0], d[1], d[2], d[3]);
+            } else {
+#pragma unroll
+              for (int t = 0; t < NT; t++) *(unsigned*)(E + p * FB_EST + 4 * NT * g + 4 * t) = d[t];
+            }
+          }
         }
       };
       if (a.rqe.full) expand_loop(std::integral_constant<int, 1>{});
@@ -284,26 +304,28 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       constexpr int KT = (KK * KK + 1) / 2;
       const unsigned char* Ein = EXPAND ? E : T0 + 64 * c;
       const int est = EXPAND ? FB_EST : a.T0S;
-      const long* wm = a.wdm + ((long)(c * 4 + wave) * KT) * 64 + lane;
+      const long* wm = wdm_ + ((long)(c * NT + wave) * KT) * 64 + lane;
       long wreg[KT];
-      int4 bqm;
-      float4 mum;
+      int4 bqm = make_int4(0, 0, 0, 0);
+      float4 mum = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool cg_active = NT == 4 || wave < NT;   // 48-channel chunks have three channel groups: wave 3 sits this stage out
       if (PREF_DW || (!EXPAND && c == 0)) {
 #pragma unroll
         for (int mi = 0; mi < KT; mi++) wreg[mi] = wpre[mi];
         bqm = bpre;
         mum = mpre;
-      } else {
+      } else if (cg_active) {
 #pragma unroll
         for (int mi = 0; mi < KT; mi++) wreg[mi] = wm[mi * 64];
-        bqm = *(const int4*)(a.bdm + c * 64 + 16 * wave + 4 * g);
-        mum = *(const float4*)(a.md + c * 64 + 16 * wave + 4 * g);
+        bqm = *(const int4*)(a.bdm + c * CH + 16 * wave + 4 * g);
+        mum = *(const float4*)(a.md + c * CH + 16 * wave + 4 * g);
       }
       const unsigned char* lane_base = Ein + 16 * wave + 8 * (g & 1);
       const int hi_half = g >> 1;
       // two slot groups at a time: their MFMA chains are independent, so one hides the other's accumulate latency
 #pragma unroll
       for (int pg = 0; pg < 4; pg += 2) {
+        if (!cg_active) break;
         v4i dqa = v4i_from(bqm), dqb = v4i_from(bqm);
         const unsigned char* pba = lane_base + hbase[pg] * est;
         const unsigned char* pbb = lane_base + hbase[pg + 1] * est;
@@ -369,12 +391,12 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       long bv = *(const long*)(D + (wave * 16 + r) * FB_DST + 32 * k2 + 8 * g);
 #pragma unroll
       for (int nb = 0; nb < NBP; nb++) {
-        const long* w = a.wp + ((long)(nb * a.KSp + 2 * c + k2) * 4) * 64 + lane;
+        const long* w = (NT == 3 ? a.wp3 + ((long)(nb * a.KSp3 + 2 * c + k2) * 4) * 64 : a.wp + ((long)(nb * a.KSp + 2 * c + k2) * 4) * 64) + lane;
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[nb][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], bv, acc[nb][t], 0, 0, 0);
       }
     }
-    if (!EXPAND && c + 1 < a.nchunks) __syncthreads();  // D is rewritten by the next chunk's depthwise
+    if (!EXPAND && c + 1 < nch) __syncthreads();  // D is rewritten by the next chunk's depthwise
   }
 
   // ---- epilogue: requantise, optional residual ADD with the block input (centre of T0), store ----
@@ -426,10 +448,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 }
 
 
-template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0>
+template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4>
 __global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem_dyn[];
-  fused_block_body<KK, S, NBP, EXPAND, MDW, KSE>(a, blockIdx.x, fb_smem_dyn);
+  fused_block_body<KK, S, NBP, EXPAND, MDW, KSE, NT>(a, blockIdx.x, fb_smem_dyn);
 }
 
 // Several independent problems (e.g. the same head layer on all 5 pyramid levels of both heads) in ONE grid:
