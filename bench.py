@@ -155,13 +155,10 @@ def main():
     pipe.finish(stream)
     # result record per clip: [best_id, n_rows, n_phases, 32 x (t0,t1,y0,y1,rom,type)]
     rec = np.zeros((n, 3 + 32 * 6), np.float64)
-    nrows = 0
-    for c in range(n):
-        best, ph = pipe.phases(c)
-        st = pipe.tracker.status(c)
-        nrows += st["rows"]
-        rec[c, 0], rec[c, 1], rec[c, 2] = best, st["rows"], len(ph)
-        rec[c, 3:3 + 6 * min(len(ph), 32)] = ph[:32].reshape(-1)
+    best, rows_n, nph, ovf, ph = pipe.tracker.summary(cap=32)       # every clip's export id / row count / phases: 4 D2H copies
+    nrows = int(rows_n.sum())
+    rec[:, 0], rec[:, 1], rec[:, 2] = best, rows_n, nph
+    rec[:, 3:] = ph.reshape(n, -1)
     if dist is not None:                                             # the one exchange of the path: RCCL all-gather
         mine = torch.from_numpy(rec).to(cdev)
         allrec = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=cdev)   # concatenated layout
@@ -178,7 +175,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    overflow = sum(pipe.tracker.status(c)["overflow"] for c in range(n))
+    overflow = int((ovf != 0).sum())
 
     roofline = None
     if rank == 0 and not args.no_roofline:

@@ -164,6 +164,9 @@ int vbt_tracker_rows(vbt_tracker* t, int clip, int64_t* id, double* cols7, int c
 int vbt_tracker_finish(vbt_tracker* t, double plate_diameter, double diff_threshold, double min_distance, void* stream);
 /* phases6 [P,6] = time_start,time_end,y_start,y_end,rom,type (reference Phase.py:16-22) */
 int vbt_tracker_phases(vbt_tracker* t, int clip, int32_t* best_id, double* phases6, int cap, int* P);
+/* The same for every clip at once (arrays of n_clips entries; phases6 is [n_clips][cap][6], rows beyond n_phases[c] are
+ * not written): export ids, DataFrame row counts, phase counts and overflow flags in four device-to-host copies. */
+int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int32_t* n_phases, int32_t* overflow, double* phases6, int cap);
 
 /* ------------------------------------------------------------------ rep analysis ------------
  * Replaces VelocityTracker (reference VelocityTracker.py:15-230) as driven by analyze_df

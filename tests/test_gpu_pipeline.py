@@ -168,3 +168,25 @@ def test_errors_are_loud(model_path):
         it.detect(np.zeros((3, 320, 320, 3), np.uint8))          # batch > max_batch
     with pytest.raises(ValueError):
         it.get_signature_runner()(images=np.zeros((1, 100, 100, 3), np.uint8))
+
+
+def test_summary_equals_per_clip_queries(model_path):
+    """vbt_tracker_summary (all clips, four copies) against vbt_tracker_phases / vbt_tracker_status clip by clip."""
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    n, T = 5, 40
+    pipe = Pipeline(model_path, n, max_frames=T, fps=60.0, detection_treshold=0.3, rows_per_frame=25)
+    st = torch.cuda.current_stream().cuda_stream
+    for t in range(T):
+        fd = torch.from_numpy(synth.batch_frames(range(20, 20 + n), 2 * t)).cuda()
+        pipe.step(fd.data_ptr(), st)
+        torch.cuda.current_stream().synchronize()
+    pipe.finish(st)
+    best, rows, nph, ovf, ph = pipe.tracker.summary(cap=48)
+    assert rows.sum() > 0
+    for c in range(n):
+        b, p = pipe.phases(c)
+        s = pipe.tracker.status(c)
+        assert (b, s["rows"], len(p)) == (best[c], rows[c], nph[c]) and ovf[c] == 0
+        assert np.array_equal(ph[c, :nph[c]], p)

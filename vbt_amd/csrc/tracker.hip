@@ -1161,4 +1161,31 @@ int vbt_window_means(const double* rows, int T, int ncols, const int32_t* window
   return VBT_OK;
 }
 
+int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int32_t* n_phases, int32_t* overflow, double* phases6, int cap) {
+  if (!t || !best_ids || !n_rows || !n_phases || !overflow || !phases6 || cap < 1) { set_error("bad argument"); return VBT_ERR_ARG; }
+  if (!t->finished) { set_error("vbt_tracker_summary before vbt_tracker_finish"); return VBT_ERR_STATE; }
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  const int n = t->n_clips;
+  std::vector<int> nph(n);
+  VBT_HIP_CHECK(hipMemcpy(nph.data(), t->nph, sizeof(int) * n, hipMemcpyDeviceToHost));
+  VBT_HIP_CHECK(hipMemcpy(best_ids, t->best, sizeof(int) * n, hipMemcpyDeviceToHost));
+  // per-clip state headers: one strided 2D copy instead of n small ones
+  const size_t hdr = offsetof(ClipState, last_out);
+  std::vector<char> heads((size_t)n * hdr);
+  VBT_HIP_CHECK(hipMemcpy2D(heads.data(), hdr, t->states, sizeof(ClipState), hdr, n, hipMemcpyDeviceToHost));
+  int most = 0;
+  for (int c = 0; c < n; c++) {
+    const ClipState* st = (const ClipState*)(heads.data() + (size_t)c * hdr);
+    n_rows[c] = st->nrows;
+    overflow[c] = st->overflow | st->rows_overflow;
+    n_phases[c] = nph[c];
+    if (nph[c] > cap) { set_error("clip %d has %d phases, buffer holds %d", c, nph[c], cap); return VBT_ERR_CAPACITY; }
+    most = std::max(most, nph[c]);
+  }
+  if (most > 0)
+    VBT_HIP_CHECK(hipMemcpy2D(phases6, sizeof(double) * 6 * cap, t->phases, sizeof(double) * 6 * MAXPH, sizeof(double) * 6 * most, n,
+                              hipMemcpyDeviceToHost));
+  return VBT_OK;
+}
+
 }  // extern "C"

@@ -97,6 +97,18 @@ class MultiClipTracker:
         return best.value, ph[:n.value].copy()
 
 
+def _summary(self, cap=64):
+    """(best_ids[n], n_rows[n], n_phases[n], overflow[n], phases[n, cap, 6]) of every clip after finish(), in one call."""
+    n = self.n_clips
+    best, rows, nph, ovf = (np.zeros(n, np.int32) for _ in range(4))
+    ph = np.zeros((n, cap, 6), np.float64)
+    _lib.check(_lib.lib().vbt_tracker_summary(self._h, best.ctypes.data, rows.ctypes.data, nph.ctypes.data, ovf.ctypes.data, ph.ctypes.data, cap))
+    return best, rows, nph, ovf, ph
+
+
+MultiClipTracker.summary = _summary
+
+
 class OCSort:
     """Single-clip tracker with the reference's call shape (reference track.py:157,186-199)."""
 
