@@ -97,7 +97,7 @@ def _cpu_name():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000, help="frames per clip inside the timed region (the reference clips hold 700-3300 frames)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU = detector batch")
     ap.add_argument("--unique-steps", type=int, default=64, help="distinct frame sets kept in HBM and cycled")
