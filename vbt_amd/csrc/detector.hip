@@ -649,7 +649,16 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
   // pass 1: histogram of the class bytes
   for (int l = 0; l < 5; l++) {
     int nl = p.base[l + 1] - p.base[l];
-    for (int i = tid; i < nl; i += 256) atomicAdd(&hist[(int)cls[l][i] + 128], 1);
+    if ((nl & 3) == 0) {  // four class bytes per load (the per-frame base stays dword-aligned)
+      const unsigned* c4 = (const unsigned*)cls[l];
+      for (int i = tid; i < (nl >> 2); i += 256) {
+        const unsigned u = c4[i];
+#pragma unroll
+        for (int e = 0; e < 4; e++) atomicAdd(&hist[(int)(int8_t)(u >> (8 * e)) + 128], 1);
+      }
+    } else {
+      for (int i = tid; i < nl; i += 256) atomicAdd(&hist[(int)cls[l][i] + 128], 1);
+    }
   }
   __syncthreads();
   int qcur = 127;   // highest class byte not yet consumed (uniform across the block)
@@ -676,11 +685,35 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
     // pass 2: collect candidate keys = (127 - q) << 16 | anchor  (ascending key = score desc, anchor asc)
     for (int l = 0; l < 5; l++) {
       int lo = max(i0, p.base[l]), hi = min(i1, p.base[l + 1]);
-      for (int i = lo + tid; i < hi; i += 256) {
-        int q = cls[l][i - p.base[l]];
-        if (q >= qlo && q <= qhi) {
-          int pos = atomicAdd(&s_n, 1);
-          keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)i;
+      const int nl = p.base[l + 1] - p.base[l];
+      if ((nl & 3) == 0 && ((lo - p.base[l]) & 3) == 0) {
+        const unsigned* c4 = (const unsigned*)(cls[l] + (lo - p.base[l]));
+        const int n4 = (hi - lo) >> 2;
+        for (int i4 = tid; i4 < n4; i4 += 256) {
+          const unsigned u = c4[i4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int q = (int)(int8_t)(u >> (8 * e));
+            if (q >= qlo && q <= qhi) {
+              int pos = atomicAdd(&s_n, 1);
+              keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)(lo + 4 * i4 + e);
+            }
+          }
+        }
+        for (int i = lo + 4 * n4 + tid; i < hi; i += 256) {
+          int q = cls[l][i - p.base[l]];
+          if (q >= qlo && q <= qhi) {
+            int pos = atomicAdd(&s_n, 1);
+            keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)i;
+          }
+        }
+      } else {
+        for (int i = lo + tid; i < hi; i += 256) {
+          int q = cls[l][i - p.base[l]];
+          if (q >= qlo && q <= qhi) {
+            int pos = atomicAdd(&s_n, 1);
+            keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)i;
+          }
         }
       }
     }
