@@ -51,3 +51,27 @@ def test_lite2_detector_and_tracker_parity(oracle_lib, lite2_model):
         assert g["id"] == want["id"]
         for k in ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width"):
             assert np.array_equal(np.asarray(g[k]), np.asarray(want[k])), (c, k)
+
+
+@pytest.mark.parametrize("flags", [8, 8 | 2048, 0])
+def test_lite1_detector_parity(oracle_lib, tmp_path_factory, flags):
+    """EfficientDet-Lite1 (384x384, BiFPN width 88 -> two 64-channel output blocks, 4 cells): every tensor that reaches
+    HBM and the detections, bit-exact against the oracle (most-fused, 48-channel chunks, autotuned)."""
+    from vbt_amd import synth
+    from vbt_amd.interpreter import Interpreter
+    global _LITE1
+    try:
+        _LITE1
+    except NameError:
+        _LITE1 = str(tmp_path_factory.mktemp("models") / "efficientdet_lite1_synth.vbtm")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_model.py"), "--arch", "1", "--out", _LITE1, "--calib", "2"])
+    frames = np.stack([synth.render(synth.background(90 + c, 384), 4 * c) for c in range(2)])
+    det = oracle_lib.OracleDetector(_LITE1)
+    it = Interpreter(_LITE1, max_batch=2, flags=flags)
+    boxes, scores, classes, counts = it.detect(frames)
+    for b in range(2):
+        ob, os_, oc, on = det.run(frames[b])
+        assert counts[b] == on and np.array_equal(scores[b], os_) and np.array_equal(boxes[b], ob)
+        for tid in range(1, it.num_tensors() - 1):
+            if it.materialized(tid):
+                assert np.array_equal(it.read_tensor(tid, 2)[b], det.tensor(tid)), (flags, tid)
