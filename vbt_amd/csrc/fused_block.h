@@ -148,7 +148,26 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       *(unsigned*)(T0 + p * a.T0S + 4 * cd) = v;
     }
   } else {
-    // plain tensor: 8-byte granules, coalesced along channels; (hy,hx) advance incrementally (no divisions in the loop)
+    // plain tensor, coalesced along channels; (hy,hx) advance incrementally (no divisions in the loop).
+    // SeparableConv tiles (rows of Cp + 16 bytes, 16-byte aligned) with Cin % 16 == 0 move 16 bytes per lane-iteration.
+    if (!EXPAND && (a.Cin & 15) == 0) {
+      const int ng = a.Cin >> 4;
+      const unsigned zb1 = (unsigned)(a.zx & 255) * 0x01010101u;
+      const uint4 zb = make_uint4(zb1, zb1, zb1, zb1);
+      const int8_t* xb = a.x + b * (long)a.H * a.W * a.Cin;
+      const int pstep = 256 / ng;
+      int p = tid / ng;
+      const int sg = tid - p * ng;
+      int hy = p / HWx, hx = p - hy * HWx;
+      for (; tid < pstep * ng && p < NPh; p += pstep) {
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        uint4 v = zb;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xb + ((long)iy * a.W + ix) * a.Cin + 16 * sg);
+        *(uint4*)(T0 + p * a.T0S + 16 * sg) = v;
+        hx += pstep;
+        while (hx >= HWx) { hx -= HWx; hy++; }
+      }
+    } else {
     const int ng = a.Cin >> 3;
     const unsigned long long zb = (unsigned long long)(a.zx & 255) * 0x0101010101010101ull;
     const int8_t* xb = a.x + b * (long)a.H * a.W * a.Cin;
@@ -163,6 +182,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       *(unsigned long long*)(T0 + p * a.T0S + 8 * sg) = v;
       hx += pstep;
       while (hx >= HWx) { hx -= HWx; hy++; }
+    }
     }
   }
   // which of this wave's halo pixel groups hold out-of-image pixels (expand epilogue), bit i <-> pg = wave + 4i
