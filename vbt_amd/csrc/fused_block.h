@@ -66,6 +66,18 @@ struct FusedArgs {
   int sum_lo, sum_hi;  // clamp of the sum (its zero point is zx)
 };
 
+// two unsigned 16-bit maxima in one VALU op (v_pk_max_u16)
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  v2u16 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  v2u16 r = __builtin_elementwise_max(x, y);
+  unsigned o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+}
+
 constexpr int FB_EST = 80;  // E tile bytes per pixel (64 + 16: bank spread, 16-B aligned)
 constexpr int FB_DST = 72;  // D tile bytes per pixel
 
@@ -119,19 +131,30 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
               else { yy = (iy * a.sh[j]) / a.H; xx = (ix * a.sw[j]) / a.W; }
               u = *(const unsigned*)(sb + ((long)yy * a.sw[j] + xx) * a.Cin);
             } else {
-              int m0 = -128, m1 = -128, m2 = -128, m3 = -128;
+              // 3x3/2 max pool read in place: nine independent loads (clamped addresses, out-of-map taps replaced by
+              // -128) so they are all in flight together; the byte-wise signed max runs on the u8 image of the values
+              // (x ^ 0x80) as two packed-u16 maxima per tap.
+              unsigned tv[9];
+#pragma unroll
               for (int ky = 0; ky < 3; ky++) {
-                int yy = iy * 2 + ky - a.spt[j];
-                if (yy < 0 || yy >= a.sh[j]) continue;
+                const int yy = iy * 2 + ky - a.spt[j];
+                const int yc = min(max(yy, 0), a.sh[j] - 1);
+#pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                  int xx = ix * 2 + kx - a.spl[j];
-                  if (xx < 0 || xx >= a.sw[j]) continue;
-                  unsigned t = *(const unsigned*)(sb + ((long)yy * a.sw[j] + xx) * a.Cin);
-                  m0 = max(m0, (int)(int8_t)(t & 255u)); m1 = max(m1, (int)(int8_t)((t >> 8) & 255u));
-                  m2 = max(m2, (int)(int8_t)((t >> 16) & 255u)); m3 = max(m3, (int)(int8_t)(t >> 24));
+                  const int xx = ix * 2 + kx - a.spl[j];
+                  const int xc = min(max(xx, 0), a.sw[j] - 1);
+                  const unsigned t = *(const unsigned*)(sb + ((long)yc * a.sw[j] + xc) * a.Cin);
+                  tv[ky * 3 + kx] = (yy == yc && xx == xc) ? (t ^ 0x80808080u) : 0u;
                 }
               }
-              u = pack4(m0, m1, m2, m3);
+              unsigned lo = 0u, hi = 0u;   // bytes 0,2 and bytes 1,3 as u16 lanes
+#pragma unroll
+              for (int q = 0; q < 9; q++) {
+                const unsigned l = tv[q] & 0x00FF00FFu, h = (tv[q] >> 8) & 0x00FF00FFu;
+                lo = pk_max_u16(lo, l);
+                hi = pk_max_u16(hi, h);
+              }
+              u = (lo | (hi << 8)) ^ 0x80808080u;
             }
 #pragma unroll
             for (int e = 0; e < 4; e++) {
