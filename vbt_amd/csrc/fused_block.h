@@ -156,9 +156,12 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
               }
               u = (lo | (hi << 8)) ^ 0x80808080u;
             }
+            // (q - z) as float: v_cvt_f32_ubyteN of the u8 image (q + 128) minus (128 + z), both exact
+            const unsigned ub = u ^ 0x80808080u;
+            const float zf = (float)(128 + a.sz[j]);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-              float f = (float)((int)(int8_t)(u >> (8 * e)) - a.sz[j]);
+              float f = (float)((ub >> (8 * e)) & 255u) - zf;
               rr[e] = j == 0 ? f * a.sk[0] : __builtin_fmaf(f, a.sk[j], rr[e]);
             }
           }
