@@ -215,12 +215,17 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   const int NPG = (NPh + 15) >> 4;
   unsigned oob_mask = 0, tail_mask = 0;
   if (EXPAND) {
+    // interior tiles (halo completely inside the image - most tiles of the large maps) have no out-of-image pixel:
+    // the per-pixel coordinate test is skipped for the whole workgroup
+    const bool border = iy0 < 0 || ix0 < 0 || iy0 + HWy > a.H || ix0 + HWx > a.W;
     for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
       int p = pg * 16 + r;
-      int pc = min(p, NPh - 1);
-      int hy = fdiv_small(pc, rcp_hwx), hx = pc - hy * HWx;
-      int iy = iy0 + hy, ix = ix0 + hx;
-      if (!(iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)) oob_mask |= 1u << i;
+      if (border) {
+        int pc = min(p, NPh - 1);
+        int hy = fdiv_small(pc, rcp_hwx), hx = pc - hy * HWx;
+        int iy = iy0 + hy, ix = ix0 + hx;
+        if (!(iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)) oob_mask |= 1u << i;
+      }
       if (p >= NPh) tail_mask |= 1u << i;
     }
   }
@@ -240,7 +245,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 #pragma unroll
     for (int pg = 0; pg < 4; pg++) {
       int slot = pg * 16 + r;
-      int sq = fdiv_small(slot, rcp_txp);
+      int sq = TXp == 8 ? (slot >> 3) : fdiv_small(slot, rcp_txp);   // 8-wide tiles (the common case): shifts only
       int py_ = min(sq, a.TY - 1), px_ = slot - sq * TXp;
       hbase[pg] = (py_ * S) * HWx + px_ * S;
     }
