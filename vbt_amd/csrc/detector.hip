@@ -2063,6 +2063,11 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + (s.family == F_MBCONV ? NPh_ * FB_EST : 0) + 64 * FB_DST;
         grid = dim3((unsigned)((long)B * a.tiles_x * a.tiles_y));
       }
+      if (nt3) {  // 72-byte E rows (fused_block.h)
+        const int TXp_ = (a.TX + 3) & ~3;
+        const int NPh_ = ((TXp_ - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
+        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * 72 + 15) & ~15) + 64 * FB_DST;
+      }
 #define FB_LAUNCH(KK, S, NBP)                                                                              \
   do {                                                                                                     \
     if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 3><<<grid, 256, lds_bytes, st>>>(a);      \

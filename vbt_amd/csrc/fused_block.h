@@ -97,7 +97,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   const float rcp_hwx = 1.0f / (float)HWx, rcp_txp = 1.0f / (float)TXp;
   unsigned char* T0 = fb_smem;
   unsigned char* E = T0 + ((NPh * a.T0S + 15) & ~15);
-  unsigned char* D = E + (EXPAND ? NPh * FB_EST : 0);
+  // 48-channel chunks keep E rows at 72 bytes: fewer bank conflicts in the depthwise reads (18-dword pixel stride: conflict-
+  // free at stride 1, 2-way at stride 2; 80 bytes gives 2-way / 4-way) and less LDS per workgroup
+  constexpr int EST = (EXPAND && NT == 3) ? 72 : FB_EST;
+  unsigned char* D = E + (EXPAND ? ((NPh * EST + 15) & ~15) : 0);
 
   // ---- stage L: input halo tile -> LDS ----
   bool summed = false;
@@ -338,7 +341,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
               *(uint4*)(E + p * FB_EST + 16 * g) = make_uint4(d[0], d[1], d[2], d[3]);
             } else {
 #pragma unroll
-              for (int t = 0; t < NT; t++) *(unsigned*)(E + p * FB_EST + 4 * NT * g + 4 * t) = d[t];
+              for (int t = 0; t < NT; t++) *(unsigned*)(E + p * EST + 4 * NT * g + 4 * t) = d[t];
             }
           }
         }
@@ -354,7 +357,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       // (8 consecutive channels of pixel p + tap) is a single ds_read_b64 from the NHWC tile.  Exact int32.
       constexpr int KT = (KK * KK + 1) / 2;
       const unsigned char* Ein = EXPAND ? E : T0 + 64 * c;
-      const int est = EXPAND ? FB_EST : a.T0S;
+      const int est = EXPAND ? EST : a.T0S;
       const long* wm = wdm_ + ((long)(c * NT + wave) * KT) * 64 + lane;
       long wreg[KT];
       int4 bqm = make_int4(0, 0, 0, 0);
@@ -395,7 +398,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       }
     } else if (dw_active) {
       const unsigned char* Ein = EXPAND ? E + 4 * cq : T0 + 64 * c + 4 * cq;
-      const int est = EXPAND ? FB_EST : a.T0S;
+      const int est = EXPAND ? EST : a.T0S;
       constexpr int IW = 3 * S + KK;
       const int Cp = a.nchunks * 64;
       const float* wd = a.wd + c * 64 + 4 * cq;
