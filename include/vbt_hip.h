@@ -142,7 +142,8 @@ int vbt_tracker_reset(vbt_tracker* t);
 int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts, const double* times, int F);
 
 /* Fused path: one frame per clip straight from vbt_detect_async's device outputs; applies the
- * detection threshold of reference odt.py:70-75 (score >= det_threshold). times_host [n_clips]. */
+ * detection threshold of reference odt.py:70-75 (score >= det_threshold). times_host [n_clips]; a negative time marks a
+ * clip that has no frame in this step (clips of different lengths batched together): its state is left untouched. */
 int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, const float* scores_dev,
                                        const int32_t* counts_dev, const double* times_host, float det_threshold,
                                        void* stream);

@@ -190,3 +190,32 @@ def test_summary_equals_per_clip_queries(model_path):
         s = pipe.tracker.status(c)
         assert (b, s["rows"], len(p)) == (best[c], rows[c], nph[c]) and ovf[c] == 0
         assert np.array_equal(ph[c, :nph[c]], p)
+
+
+def test_ragged_clips(model_path, oracle_lib):
+    """Clips of different lengths in one batch (BASELINE config 5 has 34 clips of 699-3243 frames): a clip that has
+    ended is masked out of the tracker step; every clip's rows equal the oracle run on that clip alone."""
+    import torch
+    from oracle import ocsort_np
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    lengths = [9, 5, 7]
+    n, T = len(lengths), max(lengths)
+    pipe = Pipeline(model_path, n, max_frames=T, fps=30.0, detection_treshold=0.3, rows_per_frame=25)
+    st = torch.cuda.current_stream().cuda_stream
+    clips = [synth.clip_frames(40 + c, 3 * c, lengths[c]) for c in range(n)]
+    for t in range(T):
+        batch = np.stack([clips[c][t] if t < lengths[c] else np.zeros_like(clips[c][0]) for c in range(n)])
+        fd = torch.from_numpy(batch).cuda()
+        pipe.step(fd.data_ptr(), st, active=[t < lengths[c] for c in range(n)])
+        torch.cuda.current_stream().synchronize()
+    pipe.finish(st)
+    for c in range(n):
+        ob, os_, oc, on = oracle_lib.run_batch(model_path, clips[c], threads=4)
+        dets = [np.asarray([[ob[t, i, 1], ob[t, i, 0], ob[t, i, 3], ob[t, i, 2], os_[t, i], 0.0]
+                            for i in range(on[t]) if os_[t, i] >= 0.3], np.float64).reshape(-1, 6) for t in range(lengths[c])]
+        want = ocsort_np.track_boxes(dets, [(t + 1) / 30.0 for t in range(lengths[c])])
+        got = pipe.rows(c)
+        assert got["id"] == want["id"], c
+        for k in ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width"):
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), (c, k)

@@ -643,6 +643,7 @@ __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states,
                                                               int nclips, float det_threshold, TrackParams p, double q44, double q66) {
   __shared__ StepShared sh;
   const int clip = blockIdx.x, lane = threadIdx.x;
+  if (!(times[clip] >= 0.0)) return;  // negative (or NaN) time: this clip has no frame in this step (ragged batches)
   ClipState& st = states[clip];
   if (lane == 0) {
     int n = counts[clip], m = 0, mk = 0;

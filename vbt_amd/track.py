@@ -133,11 +133,14 @@ class Pipeline:
         ev.record(T)
         self._ev_trk[k] = ev
 
-    def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False):
+    def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False, active=None):
         """frames_dev_ptr: device pointer of uint8 [n,H,W,3] (frame `frame_count+1` of every clip), valid on the
         caller's current torch stream.  src_hw=(H, W) of the source frames when they are not at the network
         resolution: the bilinear resize + truncating cast of reference odt.py:10-19 (and, with swap_rb, the
-        BGR->RGB of track.py:171) then run on the device, on the slot's stream, ahead of the detector."""
+        BGR->RGB of track.py:171) then run on the device, on the slot's stream, ahead of the detector.
+        active: optional bool [n] - clips that still have a frame in this step (clips of different lengths batched together;
+        the reference processes them one after the other, track.py:85-126).  Inactive clips keep their tracker state and
+        their frame counter; whatever sits in their slot of the frame batch is detected on but ignored."""
         torch = self._torch
         k = self.frame_count % self.depth
         self.frame_count += 1
@@ -153,7 +156,14 @@ class Pipeline:
             _lib.check(_lib.lib().vbt_resize_frames(frames_dev_ptr, self.n, int(src_hw[0]), int(src_hw[1]), 1, self._resized[k].data_ptr(),
                                                     size, size, 1, int(bool(swap_rb)), self._dev, S.cuda_stream))
             frames_dev_ptr = self._resized[k].data_ptr()
-        np.divide(float(self.frame_count), self.fps, out=self._times[k])      # time = frame_count / fps (track.py:169)
+        if active is None:
+            np.divide(float(self.frame_count), self.fps, out=self._times[k])  # time = frame_count / fps (track.py:169)
+        else:
+            act = np.asarray(active, bool)
+            self._clip_frames = getattr(self, "_clip_frames", np.zeros(self.n, np.int64))
+            self._clip_frames[act] += 1
+            np.divide(self._clip_frames.astype(np.float64), self.fps, out=self._times[k])
+            self._times[k][~act] = -1.0
         b, s, c, cnt = self._bufs[k]
         _lib.check(_lib.lib().vbt_detect_async(self.interpreters[k].handle, frames_dev_ptr, self.n, S.cuda_stream, b.data_ptr(),
                                                s.data_ptr(), c.data_ptr(), cnt.data_ptr()))
