@@ -994,7 +994,10 @@ static void choose_tile(int OH, int OW, int KK, int S, bool expand, int* TXo, in
   }
 }
 
-struct NodeSrc { int n; int tensor[3]; int mode[3]; int rs_op[3]; };
+// sources of a BiFPN node's sum.  pre_add >= 0: the sum is two chained binary ADDs (3-input sums of a TFLite graph):
+// sources 0,1 are the inputs of ops[pre_add], source 2 the other input of the final ADD, chain = 1|2 the position of the
+// partial sum among the final ADD's inputs (+1).
+struct NodeSrc { int n; int tensor[3]; int mode[3]; int rs_op[3]; int pre_add = -1; int chain = 0; };
 
 static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step* out, int sum_op = -1, const NodeSrc* ns = nullptr) {
   const OpRec& dop = m->ops[d_op];
@@ -1111,6 +1114,14 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
       if (ns->mode[j] == 2) { a.spt[j] = m->ops[ns->rs_op[j]].pad_t; a.spl[j] = m->ops[ns->rs_op[j]].pad_l; }
     }
     a.sum_lo = sop.act_min; a.sum_hi = sop.act_max;
+    if (ns->pre_add >= 0) {   // two chained binary ADDs
+      const OpRec& pre = m->ops[ns->pre_add];
+      const TensorRec& tp = m->tensors[pre.output];
+      a.chain = ns->chain;
+      a.sk[0] = pre.in_mult[0]; a.sk[1] = pre.in_mult[1]; a.sk[2] = 0.0f;
+      a.cz = tp.zero_point; a.clo = pre.act_min; a.chi = pre.act_max;
+      a.ck[0] = sop.in_mult[0]; a.ck[1] = sop.in_mult[1];
+    }
   }
   s.nbp = ps.NB <= 3 ? ps.NB : 5;
   const int TXp = (a.TX + 3) & ~3;
@@ -1119,6 +1130,7 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   // accounting = compulsory traffic of the constituent graph ops
   std::vector<int> parts{e_op, d_op, p_op, a_op, sum_op};
   if (ns) for (int j = 0; j < ns->n; j++) parts.push_back(ns->rs_op[j]);
+  if (ns) parts.push_back(ns->pre_add);
   for (int oi : parts)
     if (oi >= 0) {
       s.alg_bytes_per_frame += m->op_steps[oi].alg_bytes_per_frame;
@@ -1438,9 +1450,8 @@ static int fuse_plan(vbt_model* m) {
           consumers[ad.output] != 1 || m->tensors[ad.output].c % 4 != 0)
         continue;
       NodeSrc ns;
-      ns.n = ad.n_inputs;
-      for (int j = 0; j < ad.n_inputs; j++) {
-        int t = ad.inputs[j], pj = producer[t];
+      auto absorb = [&](int j, int t) {   // source j = tensor t, read through the resize / max pool that produced it when possible
+        const int pj = producer[t];
         ns.tensor[j] = t; ns.mode[j] = 0; ns.rs_op[j] = -1;
         if (pj >= 0 && consumers[t] == 1 && (m->ops[pj].type == OP_RESIZE_NN || (m->ops[pj].type == OP_MAXPOOL && m->ops[pj].k == 3 && m->ops[pj].stride == 2))) {
           ns.tensor[j] = m->ops[pj].inputs[0];
@@ -1448,6 +1459,24 @@ static int fuse_plan(vbt_model* m) {
           ns.rs_op[j] = pj;
           absorbed[pj] = 1;
         }
+      };
+      int pre = -1, pos = 0;
+      if (ad.n_inputs == 2 && i >= 1)
+        for (int j = 0; j < 2; j++) {
+          const int pj = producer[ad.inputs[j]];
+          if (pj == i - 1 && m->ops[pj].type == OP_ADD && m->ops[pj].n_inputs == 2 && consumers[ad.inputs[j]] == 1) { pre = pj; pos = j; }
+        }
+      if (pre >= 0) {
+        ns.n = 3;
+        ns.pre_add = pre;
+        ns.chain = pos + 1;
+        absorb(0, m->ops[pre].inputs[0]);
+        absorb(1, m->ops[pre].inputs[1]);
+        absorb(2, ad.inputs[1 - pos]);
+        absorbed[pre] = 1;
+      } else {
+        ns.n = ad.n_inputs;
+        for (int j = 0; j < ad.n_inputs; j++) absorb(j, ad.inputs[j]);
       }
       node_of[i] = ns;
       is_node[i] = 1;
@@ -1462,6 +1491,7 @@ static int fuse_plan(vbt_model* m) {
       Alt unf, a1, a2;
       for (int j = 0; j < ns.n; j++)
         if (ns.rs_op[j] >= 0) { unf.steps.push_back(m->op_steps[ns.rs_op[j]]); a1.steps.push_back(m->op_steps[ns.rs_op[j]]); }
+      if (ns.pre_add >= 0) { unf.steps.push_back(m->op_steps[ns.pre_add]); a1.steps.push_back(m->op_steps[ns.pre_add]); }
       unf.steps.push_back(m->op_steps[i]);
       unf.steps.push_back(m->op_steps[i + 1]);
       unf.steps.push_back(m->op_steps[i + 2]);
@@ -1481,6 +1511,7 @@ static int fuse_plan(vbt_model* m) {
         a2.steps.push_back(s2);
         for (int j = 0; j < ns.n; j++)
           if (ns.rs_op[j] >= 0) a2.hidden.push_back(m->ops[ns.rs_op[j]].output);
+        if (ns.pre_add >= 0) a2.hidden.push_back(m->ops[ns.pre_add].output);
         a2.hidden.push_back(op.output);
         a2.hidden.push_back(m->ops[i + 1].output);
         g.alts.push_back(a2);
@@ -1598,7 +1629,7 @@ static int chain_nodes(vbt_model* m) {
     const Step& st = fa.steps[0];
     const OpRec& d = m->ops[st.d_op];
     const int HW = st.fa.H * st.fa.W, NB = (st.fa.Cout + 63) / 64;
-    return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= 400 &&
+    return st.fa.chain == 0 && d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= 400 &&
            ((HW + 15) / 16) * NB <= NC_WAVES * NC_MAXU && st.fa.Cin % 4 == 0;
   };
   auto outputs_of = [&](const Group& g, std::set<int>& acc) {

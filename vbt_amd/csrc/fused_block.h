@@ -64,6 +64,10 @@ struct FusedArgs {
   int sh[3], sw[3], smode[3], spt[3], spl[3], sz[3];
   float sk[3];
   int sum_lo, sum_hi;  // clamp of the sum (its zero point is zx)
+  // chained binary ADDs (a 3-input sum of a TFLite graph): p = requant(src0, src1) with its own quantisation (cz, clo, chi),
+  // then the tile = requant(p, src2) (chain == 1) or requant(src2, p) (chain == 2) with multipliers ck[0], ck[1] in that order
+  int chain, cz, clo, chi;
+  float ck[2];
 };
 
 // two unsigned 16-bit maxima in one VALU op (v_pk_max_u16)
@@ -162,10 +166,21 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
             // (q - z) as float: v_cvt_f32_ubyteN of the u8 image (q + 128) minus (128 + z), both exact
             const unsigned ub = u ^ 0x80808080u;
             const float zf = (float)(128 + a.sz[j]);
+            if (a.chain && j == 2) {
+              // third source of a chained sum: first requantise the partial sum of sources 0 and 1, then add in ADD order
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-              float f = (float)((ub >> (8 * e)) & 255u) - zf;
-              rr[e] = j == 0 ? f * a.sk[0] : __builtin_fmaf(f, a.sk[j], rr[e]);
+              for (int e = 0; e < 4; e++) {
+                const int q1 = min(max((int)__builtin_rintf(rr[e]) + a.cz, a.clo), a.chi);
+                const float fp = (float)(q1 - a.cz);
+                const float fc = (float)((ub >> (8 * e)) & 255u) - zf;
+                rr[e] = a.chain == 1 ? __builtin_fmaf(fc, a.ck[1], fp * a.ck[0]) : __builtin_fmaf(fp, a.ck[1], fc * a.ck[0]);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                float f = (float)((ub >> (8 * e)) & 255u) - zf;
+                rr[e] = j == 0 ? f * a.sk[0] : __builtin_fmaf(f, a.sk[j], rr[e]);
+              }
             }
           }
         }
