@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--unique-steps", type=int, default=64, help="distinct frame sets kept in HBM and cycled")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--seed-offset", type=int, default=0, help="rehearsal: run this rank on the clips another rank would own")
     args = ap.parse_args()
 
     import torch
@@ -135,9 +136,9 @@ def main():
     from vbt_amd.track import Pipeline
     n, K, W = args.clips, args.steps, args.warmup
     U = max(1, min(args.unique_steps, K + W))
-    seeds = [rank * n + c for c in range(n)]                        # ranks own disjoint clips
+    seeds = [(rank + args.seed_offset) * n + c for c in range(n)]   # ranks own disjoint clips
     frames = torch.from_numpy(make_frames(seeds, 0, U)).to(dev)      # resident in HBM before timing
-    pipe = Pipeline(MODEL, n, max_frames=K + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank)
+    pipe = Pipeline(MODEL, n, max_frames=K + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
     stream = torch.cuda.current_stream().cuda_stream
     fbytes = frames[0].numel()
 
@@ -155,10 +156,10 @@ def main():
     pipe.finish(stream)
     # result record per clip: [best_id, n_rows, n_phases, 32 x (t0,t1,y0,y1,rom,type)]
     rec = np.zeros((n, 3 + 32 * 6), np.float64)
-    best, rows_n, nph, ovf, ph = pipe.tracker.summary(cap=32)       # every clip's export id / row count / phases: 4 D2H copies
+    best, rows_n, nph, ovf, ph = pipe.tracker.summary(cap=512)      # every clip's export id / row count / phases: 4 D2H copies
     nrows = int(rows_n.sum())
     rec[:, 0], rec[:, 1], rec[:, 2] = best, rows_n, nph
-    rec[:, 3:] = ph.reshape(n, -1)
+    rec[:, 3:] = ph[:, :32].reshape(n, -1)                          # the fixed-size record keeps the first 32 phases
     if dist is not None:                                             # the one exchange of the path: RCCL all-gather
         mine = torch.from_numpy(rec).to(cdev)
         allrec = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=cdev)   # concatenated layout
