@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU = detector batch")
     ap.add_argument("--unique-steps", type=int, default=64, help="distinct frame sets kept in HBM and cycled")
-    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=2048, help="frames of the CPU baseline sample, about 15-20 s of CPU work (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed-offset", type=int, default=0, help="rehearsal: run this rank on the clips another rank would own")
     args = ap.parse_args()
