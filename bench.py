@@ -33,7 +33,8 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROAR
 # summaries under profiles/) executes the same kernels; a different batch size or missing file re-tunes.
 os.environ.setdefault("VBT_PLAN_FILE", os.path.join(ROOT, "profiles", "plan_lite0"))
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
-MODEL = os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm")
+# VBT_BENCH_MODEL: rehearsal knob (e.g. a Lite2 container for BASELINE config 4); the contract line is always Lite0
+MODEL = os.environ.get("VBT_BENCH_MODEL", os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm"))
 
 
 def make_frames(clip_seeds, t0, n_steps, size=320):
@@ -137,7 +138,9 @@ def main():
     n, K, W = args.clips, args.steps, args.warmup
     U = max(1, min(args.unique_steps, K + W))
     seeds = [(rank + args.seed_offset) * n + c for c in range(n)]   # ranks own disjoint clips
-    frames = torch.from_numpy(make_frames(seeds, 0, U)).to(dev)      # resident in HBM before timing
+    from vbt_amd.container import Container
+    size = int(Container(MODEL).header["image_size"])
+    frames = torch.from_numpy(make_frames(seeds, 0, U, size)).to(dev)  # resident in HBM before timing
     pipe = Pipeline(MODEL, n, max_frames=K + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
     stream = torch.cuda.current_stream().cuda_stream
     fbytes = frames[0].numel()
