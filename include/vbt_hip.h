@@ -147,6 +147,13 @@ int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts
 int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, const float* scores_dev,
                                        const int32_t* counts_dev, const double* times_host, float det_threshold,
                                        void* stream);
+/* The same with fewer detector slots than clips: slot i of the batch carries a frame of clip clip_of_slot_host[i]
+ * (-1: none), times_host is per slot.  A slot can move on to the next clip of its queue when one ends, so a corpus of
+ * clips of different lengths keeps every slot of the detector batch busy (the reference runs clips one after the other,
+ * track.py:85-126).  Export ids / rows / phases stay per clip. */
+int vbt_tracker_update_from_slots(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
+                                  const int32_t* clip_of_slot_host, const double* times_host, int n_slots, float det_threshold,
+                                  void* stream);
 
 /* What OCSort.update returned for the clip's most recent stepped frame: out7 [M,7] =
  * x1,y1,x2,y2,id(1-based),cls,score (reference track.py:190) and vel2 [M,2] = kf.x[4:6] of the

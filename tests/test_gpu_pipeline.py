@@ -219,3 +219,34 @@ def test_ragged_clips(model_path, oracle_lib):
         assert got["id"] == want["id"], c
         for k in ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width"):
             assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), (c, k)
+
+
+def test_slot_reuse_equals_per_clip_runs(model_path, oracle_lib):
+    """Five clips of different lengths through TWO detector slots (a slot takes the next clip of its queue when one ends,
+    vbt_tracker_update_from_slots): every clip's rows equal the oracle run on that clip alone."""
+    import torch
+    from oracle import ocsort_np
+    from vbt_amd import shard, synth
+    from vbt_amd.track import Pipeline
+    lengths = [7, 4, 6, 3, 5]
+    fps = [30.0, 60.0, 30.0, 30.0, 60.0]
+    clips = [synth.clip_frames(60 + c, 2 * c, lengths[c]) for c in range(len(lengths))]
+    cmap, fidx = shard.slot_schedule(lengths, 2)
+    assert (cmap >= 0).sum() == sum(lengths) and len(cmap) == 14          # LPT queues {7, 4, 3} and {6, 5}: makespan 14
+    pipe = Pipeline(model_path, 2, max_frames=max(lengths), fps=fps, detection_treshold=0.3, rows_per_frame=25, tracker_clips=len(lengths))
+    st = torch.cuda.current_stream().cuda_stream
+    for t in range(len(cmap)):
+        batch = np.stack([clips[cmap[t, s]][fidx[t, s] - 1] if cmap[t, s] >= 0 else np.zeros((320, 320, 3), np.uint8) for s in range(2)])
+        fd = torch.from_numpy(batch).cuda()
+        pipe.step(fd.data_ptr(), st, clip_map=cmap[t], frame_idx=fidx[t])
+        torch.cuda.current_stream().synchronize()
+    pipe.finish(st)
+    for c in range(len(lengths)):
+        ob, os_, oc, on = oracle_lib.run_batch(model_path, clips[c], threads=4)
+        dets = [np.asarray([[ob[t, i, 1], ob[t, i, 0], ob[t, i, 3], ob[t, i, 2], os_[t, i], 0.0]
+                            for i in range(on[t]) if os_[t, i] >= 0.3], np.float64).reshape(-1, 6) for t in range(lengths[c])]
+        want = ocsort_np.track_boxes(dets, [(t + 1) / fps[c] for t in range(lengths[c])])
+        got = pipe.rows(c)
+        assert got["id"] == want["id"], c
+        for k in ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width"):
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), (c, k)

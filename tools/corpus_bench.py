@@ -40,24 +40,42 @@ def main():
     n = len(mine)
     lengths = np.array([clips[k][0] for k in mine])
     fps = np.array([clips[k][1] for k in mine])
-    T, U = int(lengths.max()), 8
-    frames = torch.from_numpy(np.stack([np.stack([synth.render(synth.background(int(k), 320), 7 * u) for k in mine]) for u in range(U)])).cuda()
-    pipe = Pipeline(MODEL, n, max_frames=T, fps=fps, detection_treshold=0.5)
+    U = 8
+    slots = int(os.environ.get("VBT_CORPUS_SLOTS", "0")) or n         # 0 / unset: one slot per clip (ragged batch)
+    frames = torch.from_numpy(np.stack([np.stack([synth.render(synth.background(int(k), 320), 7 * u) for u in range(U)]) for k in mine])).cuda()  # [clip][U]
     st = torch.cuda.current_stream().cuda_stream
-    fb = frames[0].numel()
-    for t in range(6):                         # warm-up on a throw-away pipeline state is not possible: use masked steps
-        pipe.step(frames.data_ptr() + (t % U) * fb, st, active=np.zeros(n, bool))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(T):
-        pipe.step(frames.data_ptr() + (t % U) * fb, st, active=t < lengths)
+    if slots >= n:
+        T = int(lengths.max())
+        pipe = Pipeline(MODEL, n, max_frames=T, fps=fps, detection_treshold=0.5)
+        fr = frames.transpose(0, 1).contiguous()                       # [U][clip]
+        fb = fr[0].numel()
+        for t in range(6):
+            pipe.step(fr.data_ptr() + (t % U) * fb, st, active=np.zeros(n, bool))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(T):
+            pipe.step(fr.data_ptr() + (t % U) * fb, st, active=t < lengths)
+    else:
+        cmap, fidx = shard.slot_schedule(lengths, slots)
+        T = len(cmap)
+        pipe = Pipeline(MODEL, slots, max_frames=int(lengths.max()), fps=fps, detection_treshold=0.5, tracker_clips=n)
+        cm_dev = torch.from_numpy(np.maximum(cmap, 0).astype(np.int64)).cuda()
+        bufs = [torch.empty((slots, 320, 320, 3), dtype=torch.uint8, device="cuda") for _ in range(pipe.depth + 1)]
+        for t in range(6):
+            pipe.step(bufs[0].data_ptr(), st, clip_map=np.full(slots, -1), frame_idx=np.zeros(slots))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(T):
+            buf = bufs[t % len(bufs)]
+            torch.index_select(frames[:, t % U], 0, cm_dev[t], out=buf)   # this step's frame of the clip sitting in each slot
+            pipe.step(buf.data_ptr(), st, clip_map=cmap[t], frame_idx=fidx[t])
     pipe.finish(st)
     best, rows, nph, ovf, ph = pipe.tracker.summary(cap=512)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     total = int(lengths.sum())
-    print(json.dumps({"rank": rank, "world": world, "clips": n, "frames": total, "longest_clip": T, "seconds": round(dt, 3),
-                      "frames_per_s": round(total / dt), "batch_slots_per_s": round(n * T / dt), "rows": int(rows.sum()),
+    print(json.dumps({"rank": rank, "world": world, "clips": n, "frames": total, "steps": T, "slots": slots, "seconds": round(dt, 3),
+                      "frames_per_s": round(total / dt), "slot_steps_per_s": round(slots * T / dt), "rows": int(rows.sum()),
                       "overflow": int((ovf != 0).sum())}))
 
 

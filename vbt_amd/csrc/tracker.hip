@@ -638,21 +638,24 @@ __global__ __launch_bounds__(64) void tracker_kernel(ClipState* states, Row* row
 
 // ... or straight from the detector's device outputs (fused pipeline): applies the detection
 // threshold of reference odt.py:70-75 and the reorder of odt.py:102-118.
+// slot = position in the detector batch; clip = tracker state it feeds (map == nullptr: the same index; a negative entry
+// or a negative time: the slot carries no frame in this step)
 __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states, Row* rows, int rows_cap, const float* boxes,
                                                               const float* scores, const int* counts, const double* times,
-                                                              int nclips, float det_threshold, TrackParams p, double q44, double q66) {
+                                                              const int* map, float det_threshold, TrackParams p, double q44, double q66) {
   __shared__ StepShared sh;
-  const int clip = blockIdx.x, lane = threadIdx.x;
-  if (!(times[clip] >= 0.0)) return;  // negative (or NaN) time: this clip has no frame in this step (ragged batches)
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  const int clip = map ? map[slot] : slot;
+  if (clip < 0 || !(times[slot] >= 0.0)) return;
   ClipState& st = states[clip];
   if (lane == 0) {
-    int n = counts[clip], m = 0, mk = 0;
+    int n = counts[slot], m = 0, mk = 0;
     for (int i = 0; i < n && i < MAXD; i++) {
-      float s = scores[clip * MAXD + i];
+      float s = scores[slot * MAXD + i];
       if (s >= det_threshold) {
         mk++;
         if ((double)s > p.det_thresh) {
-          const float* b = boxes + ((size_t)clip * MAXD + i) * 4;  // ymin,xmin,ymax,xmax
+          const float* b = boxes + ((size_t)slot * MAXD + i) * 4;  // ymin,xmin,ymax,xmax
           sh.det[m][0] = (double)b[1]; sh.det[m][1] = (double)b[0]; sh.det[m][2] = (double)b[3]; sh.det[m][3] = (double)b[2];
           sh.det[m][4] = (double)s; sh.det[m][5] = 0.0;
           m++;
@@ -663,7 +666,7 @@ __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states,
   }
   __syncthreads();
   if (sh.flag < 0) return;
-  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, sh.flag, times[clip], p, q44, q66, lane);
+  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, sh.flag, times[slot], p, q44, q66, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -913,6 +916,7 @@ struct vbt_tracker {
   int* T = nullptr;
   int* best = nullptr;
   double* d_times = nullptr;  // [n_clips]
+  int* d_map = nullptr;       // [n_clips] slot -> clip of the current step (vbt_tracker_update_from_slots)
   bool finished = false;
 };
 
@@ -950,6 +954,7 @@ int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* prm,
   if (hipMalloc((void**)&t->T, sizeof(int) * n_clips) != hipSuccess) return fail("T");
   if (hipMalloc((void**)&t->best, sizeof(int) * n_clips) != hipSuccess) return fail("best");
   if (hipMalloc((void**)&t->d_times, sizeof(double) * n_clips) != hipSuccess) return fail("times");
+  if (hipMalloc((void**)&t->d_map, sizeof(int) * n_clips) != hipSuccess) return fail("map");
   init_states_kernel<<<(n_clips + 63) / 64, 64>>>(t->states, n_clips);
   VBT_HIP_CHECK(hipDeviceSynchronize());
   *out = t;
@@ -959,7 +964,7 @@ int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* prm,
 void vbt_tracker_destroy(vbt_tracker* t) {
   if (!t) return;
   (void)hipFree(t->states); (void)hipFree(t->rows); (void)hipFree(t->cols); (void)hipFree(t->scratch);
-  (void)hipFree(t->phases); (void)hipFree(t->nph); (void)hipFree(t->T); (void)hipFree(t->best); (void)hipFree(t->d_times);
+  (void)hipFree(t->phases); (void)hipFree(t->nph); (void)hipFree(t->T); (void)hipFree(t->best); (void)hipFree(t->d_times); (void)hipFree(t->d_map);
   delete t;
 }
 
@@ -996,7 +1001,29 @@ int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, c
   hipStream_t st = (hipStream_t)stream;
   VBT_HIP_CHECK(hipMemcpyAsync(t->d_times, times_host, sizeof(double) * t->n_clips, hipMemcpyHostToDevice, st));
   tracker_from_det_kernel<<<t->n_clips, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, t->d_times,
-                                                     t->n_clips, det_threshold, t->p, t->q44, t->q66);
+                                                     nullptr, det_threshold, t->p, t->q44, t->q66);
+  VBT_HIP_CHECK(hipGetLastError());
+  t->finished = false;
+  return VBT_OK;
+}
+
+int vbt_tracker_update_from_slots(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
+                                  const int32_t* clip_of_slot_host, const double* times_host, int n_slots, float det_threshold,
+                                  void* stream) {
+  if (!t || !boxes_dev || !scores_dev || !counts_dev || !clip_of_slot_host || !times_host || n_slots < 1 || n_slots > t->n_clips) {
+    set_error("vbt_tracker_update_from_slots: bad argument (n_slots must be in [1, n_clips])");
+    return VBT_ERR_ARG;
+  }
+  for (int i = 0; i < n_slots; i++) {
+    if (clip_of_slot_host[i] >= t->n_clips) { set_error("slot %d -> clip %d, tracker has %d clips", i, clip_of_slot_host[i], t->n_clips); return VBT_ERR_ARG; }
+    for (int j = 0; j < i; j++)
+      if (clip_of_slot_host[i] >= 0 && clip_of_slot_host[i] == clip_of_slot_host[j]) { set_error("clip %d sits in two slots", clip_of_slot_host[i]); return VBT_ERR_ARG; }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  VBT_HIP_CHECK(hipMemcpyAsync(t->d_times, times_host, sizeof(double) * n_slots, hipMemcpyHostToDevice, st));
+  VBT_HIP_CHECK(hipMemcpyAsync(t->d_map, clip_of_slot_host, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  tracker_from_det_kernel<<<n_slots, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, t->d_times, t->d_map,
+                                                  det_threshold, t->p, t->q44, t->q66);
   VBT_HIP_CHECK(hipGetLastError());
   t->finished = false;
   return VBT_OK;

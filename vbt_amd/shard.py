@@ -17,6 +17,24 @@ def shard_clips(work, world):
     return shards
 
 
+def slot_schedule(lengths, n_slots):
+    """Clips of `lengths[c]` frames run through `n_slots` detector slots: LPT assignment of clips to slot queues, a slot
+    starts its next clip the step after the previous one ended.  Returns (clip_map [T, n_slots] int32 with -1 for idle,
+    frame_idx [T, n_slots] int32, 1-based), T = makespan in steps."""
+    queues = shard_clips({c: int(n) for c, n in enumerate(lengths)}, n_slots)
+    T = max(sum(lengths[c] for c in q) for q in queues) if queues else 0
+    cmap = np.full((T, n_slots), -1, np.int32)
+    fidx = np.zeros((T, n_slots), np.int32)
+    for s, q in enumerate(queues):
+        t = 0
+        for c in q:
+            n = int(lengths[c])
+            cmap[t:t + n, s] = c
+            fidx[t:t + n, s] = np.arange(1, n + 1)
+            t += n
+    return cmap, fidx
+
+
 def gather_records(rec, dist, pad_to):
     """rec: tensor [n_i, k] of this rank's records (n_i <= pad_to).  Returns the valid rows of all ranks
     (numpy) on every rank via ONE all_gather of equal-size blocks (row 0 of each block carries n_i)."""

@@ -94,10 +94,12 @@ class Pipeline:
     recover most of that without changing the per-step batch."""
 
     def __init__(self, model_path, n_clips, max_frames, fps=60.0, detection_treshold=0.5, device=0, rows_per_frame=4,
-                 plate_diameter=0.45, depth=None):
+                 plate_diameter=0.45, depth=None, tracker_clips=None):
         import torch
-        self.n = int(n_clips)
-        self.fps = np.broadcast_to(np.asarray(fps, np.float64), (self.n,)).copy()
+        self.n = int(n_clips)                       # slots of the detector batch
+        # tracker_clips > n_clips: more clips than batch slots; step(clip_map=...) says which clip sits in which slot
+        self.n_trk = int(tracker_clips) if tracker_clips is not None else self.n
+        self.fps = np.broadcast_to(np.asarray(fps, np.float64), (self.n_trk,)).copy()
         self.thr = float(detection_treshold)
         self.plate_diameter = plate_diameter
         self.depth = int(depth if depth is not None else os.environ.get("VBT_PIPELINE_DEPTH", "3"))
@@ -107,7 +109,7 @@ class Pipeline:
         tdev = torch.device(f"cuda:{device}")
         self.interpreters = [Interpreter(model_path, device=device, max_batch=self.n) for _ in range(self.depth)]
         self.interpreter = self.interpreters[0]
-        self.tracker = MultiClipTracker(self.n, int(max_frames) * rows_per_frame + 3 * 25, max_age=MAX_AGE,   # frames 1-3 may emit 25 rows each
+        self.tracker = MultiClipTracker(self.n_trk, int(max_frames) * rows_per_frame + 3 * 25, max_age=MAX_AGE,   # frames 1-3 may emit 25 rows each
                                         asso_func="diou", iou_threshold=0.1, device=device)
         self.frame_count = 0
         n = self.n
@@ -115,6 +117,7 @@ class Pipeline:
                        torch.empty((n, 25), dtype=torch.float32, device=tdev), torch.empty((n,), dtype=torch.int32, device=tdev))
                       for _ in range(self.depth)]
         self._times = [np.zeros(n, np.float64) for _ in range(self.depth)]
+        self._maps = [None] * self.depth             # per-slot clip maps of the steps in flight
         self._det_streams = [torch.cuda.Stream(device=tdev) for _ in range(self.depth)]
         self._trk_stream = torch.cuda.Stream(device=tdev)
         self._ev_in = [torch.cuda.Event() for _ in range(self.depth)]
@@ -127,20 +130,28 @@ class Pipeline:
         T = self._trk_stream
         T.wait_event(self._ev_det[k])
         b, s, c, cnt = self._bufs[k]
-        _lib.check(_lib.lib().vbt_tracker_update_from_detections(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
-                                                                 self._times[k].ctypes.data, self.thr, T.cuda_stream))
+        if self._maps[k] is not None:
+            _lib.check(_lib.lib().vbt_tracker_update_from_slots(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
+                                                                self._maps[k].ctypes.data, self._times[k].ctypes.data, self.n, self.thr,
+                                                                T.cuda_stream))
+        else:
+            _lib.check(_lib.lib().vbt_tracker_update_from_detections(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
+                                                                     self._times[k].ctypes.data, self.thr, T.cuda_stream))
         ev = self._torch.cuda.Event()
         ev.record(T)
         self._ev_trk[k] = ev
 
-    def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False, active=None):
+    def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False, active=None, clip_map=None, frame_idx=None):
         """frames_dev_ptr: device pointer of uint8 [n,H,W,3] (frame `frame_count+1` of every clip), valid on the
         caller's current torch stream.  src_hw=(H, W) of the source frames when they are not at the network
         resolution: the bilinear resize + truncating cast of reference odt.py:10-19 (and, with swap_rb, the
         BGR->RGB of track.py:171) then run on the device, on the slot's stream, ahead of the detector.
         active: optional bool [n] - clips that still have a frame in this step (clips of different lengths batched together;
         the reference processes them one after the other, track.py:85-126).  Inactive clips keep their tracker state and
-        their frame counter; whatever sits in their slot of the frame batch is detected on but ignored."""
+        their frame counter; whatever sits in their slot of the frame batch is detected on but ignored.
+        clip_map / frame_idx: int [n] - slot i carries frame number frame_idx[i] (1-based) of tracker clip clip_map[i] (-1:
+        empty slot).  With tracker_clips > n_clips a slot moves on to the next clip of its queue when one ends, so a corpus
+        of ragged clips keeps the whole detector batch busy."""
         torch = self._torch
         k = self.frame_count % self.depth
         self.frame_count += 1
@@ -156,7 +167,13 @@ class Pipeline:
             _lib.check(_lib.lib().vbt_resize_frames(frames_dev_ptr, self.n, int(src_hw[0]), int(src_hw[1]), 1, self._resized[k].data_ptr(),
                                                     size, size, 1, int(bool(swap_rb)), self._dev, S.cuda_stream))
             frames_dev_ptr = self._resized[k].data_ptr()
-        if active is None:
+        self._maps[k] = None
+        if clip_map is not None:
+            cm = np.ascontiguousarray(clip_map, dtype=np.int32)
+            fi = np.asarray(frame_idx, np.float64)
+            self._maps[k] = cm
+            self._times[k][:] = np.where(cm >= 0, fi / self.fps[np.maximum(cm, 0)], -1.0)
+        elif active is None:
             np.divide(float(self.frame_count), self.fps, out=self._times[k])  # time = frame_count / fps (track.py:169)
         else:
             act = np.asarray(active, bool)
