@@ -180,7 +180,7 @@ def test_summary_equals_per_clip_queries(model_path):
     st = torch.cuda.current_stream().cuda_stream
     for t in range(T):
         fd = torch.from_numpy(synth.batch_frames(range(20, 20 + n), 2 * t)).cuda()
-        pipe.step(fd.data_ptr(), st)
+        pipe.step(fd, st)
         torch.cuda.current_stream().synchronize()
     pipe.finish(st)
     best, rows, nph, ovf, ph = pipe.tracker.summary(cap=48)
@@ -207,7 +207,7 @@ def test_ragged_clips(model_path, oracle_lib):
     for t in range(T):
         batch = np.stack([clips[c][t] if t < lengths[c] else np.zeros_like(clips[c][0]) for c in range(n)])
         fd = torch.from_numpy(batch).cuda()
-        pipe.step(fd.data_ptr(), st, active=[t < lengths[c] for c in range(n)])
+        pipe.step(fd, st, active=[t < lengths[c] for c in range(n)])
         torch.cuda.current_stream().synchronize()
     pipe.finish(st)
     for c in range(n):
@@ -238,7 +238,7 @@ def test_slot_reuse_equals_per_clip_runs(model_path, oracle_lib):
     for t in range(len(cmap)):
         batch = np.stack([clips[cmap[t, s]][fidx[t, s] - 1] if cmap[t, s] >= 0 else np.zeros((320, 320, 3), np.uint8) for s in range(2)])
         fd = torch.from_numpy(batch).cuda()
-        pipe.step(fd.data_ptr(), st, clip_map=cmap[t], frame_idx=fidx[t])
+        pipe.step(fd, st, clip_map=cmap[t], frame_idx=fidx[t])
         torch.cuda.current_stream().synchronize()
     pipe.finish(st)
     for c in range(len(lengths)):

@@ -60,15 +60,14 @@ def main():
         T = len(cmap)
         pipe = Pipeline(MODEL, slots, max_frames=int(lengths.max()), fps=fps, detection_treshold=0.5, tracker_clips=n)
         cm_dev = torch.from_numpy(np.maximum(cmap, 0).astype(np.int64)).cuda()
-        bufs = [torch.empty((slots, 320, 320, 3), dtype=torch.uint8, device="cuda") for _ in range(pipe.depth + 1)]
+        idle = torch.zeros((slots, 320, 320, 3), dtype=torch.uint8, device="cuda")
         for t in range(6):
-            pipe.step(bufs[0].data_ptr(), st, clip_map=np.full(slots, -1), frame_idx=np.zeros(slots))
+            pipe.step(idle, st, clip_map=np.full(slots, -1), frame_idx=np.zeros(slots))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for t in range(T):
-            buf = bufs[t % len(bufs)]
-            torch.index_select(frames[:, t % U], 0, cm_dev[t], out=buf)   # this step's frame of the clip sitting in each slot
-            pipe.step(buf.data_ptr(), st, clip_map=cmap[t], frame_idx=fidx[t])
+            buf = torch.index_select(frames[:, t % U], 0, cm_dev[t])      # this step's frame of the clip sitting in each slot
+            pipe.step(buf, st, clip_map=cmap[t], frame_idx=fidx[t])          # (a tensor: Pipeline ties its lifetime to the slot's stream)
     pipe.finish(st)
     best, rows, nph, ovf, ph = pipe.tracker.summary(cap=512)
     torch.cuda.synchronize()

@@ -51,8 +51,7 @@ def track(src, model, detection_treshold, df_dir, fps, frame_stride):
                 pipe.frame_count += 1                                    # skipped frames still advance time (track.py:161-169)
                 continue
             fd = torch.from_numpy(np.ascontiguousarray(frames[t:t + 1])).cuda()
-            pipe.step(fd.data_ptr(), st, src_hw=(H, W))
-            torch.cuda.current_stream().synchronize()
+            pipe.step(fd, st, src_hw=(H, W))
         pipe.finish(st)
         data = pipe.rows(0)
         if not data["id"]:

@@ -118,6 +118,7 @@ class Pipeline:
                       for _ in range(self.depth)]
         self._times = [np.zeros(n, np.float64) for _ in range(self.depth)]
         self._maps = [None] * self.depth             # per-slot clip maps of the steps in flight
+        self._host_ring = []                         # host arrays handed to asynchronous copies (see _enqueue_tracker)
         self._det_streams = [torch.cuda.Stream(device=tdev) for _ in range(self.depth)]
         self._trk_stream = torch.cuda.Stream(device=tdev)
         self._ev_in = [torch.cuda.Event() for _ in range(self.depth)]
@@ -130,20 +131,27 @@ class Pipeline:
         T = self._trk_stream
         T.wait_event(self._ev_det[k])
         b, s, c, cnt = self._bufs[k]
-        if self._maps[k] is not None:
+        # the library copies these small host arrays with hipMemcpyAsync; private copies that nothing overwrites (kept for the
+        # next 32 tracker steps) make that safe whether the runtime stages pageable memory at call time or not
+        tm = self._times[k].copy()
+        mp = self._maps[k].copy() if self._maps[k] is not None else None
+        self._host_ring.append((tm, mp))
+        if len(self._host_ring) > 32:
+            self._host_ring.pop(0)
+        if mp is not None:
             _lib.check(_lib.lib().vbt_tracker_update_from_slots(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
-                                                                self._maps[k].ctypes.data, self._times[k].ctypes.data, self.n, self.thr,
-                                                                T.cuda_stream))
+                                                                mp.ctypes.data, tm.ctypes.data, self.n, self.thr, T.cuda_stream))
         else:
             _lib.check(_lib.lib().vbt_tracker_update_from_detections(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
-                                                                     self._times[k].ctypes.data, self.thr, T.cuda_stream))
+                                                                     tm.ctypes.data, self.thr, T.cuda_stream))
         ev = self._torch.cuda.Event()
         ev.record(T)
         self._ev_trk[k] = ev
 
     def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False, active=None, clip_map=None, frame_idx=None):
-        """frames_dev_ptr: device pointer of uint8 [n,H,W,3] (frame `frame_count+1` of every clip), valid on the
-        caller's current torch stream.  src_hw=(H, W) of the source frames when they are not at the network
+        """frames_dev_ptr: uint8 [n,H,W,3] on the device (frame `frame_count+1` of every clip), valid on the caller's current
+        torch stream: either a torch tensor (preferred: its lifetime is then handled here) or a raw device pointer, which
+        the caller must keep alive and unmodified until the step has run (up to `depth` steps later).  src_hw=(H, W) of the source frames when they are not at the network
         resolution: the bilinear resize + truncating cast of reference odt.py:10-19 (and, with swap_rb, the
         BGR->RGB of track.py:171) then run on the device, on the slot's stream, ahead of the detector.
         active: optional bool [n] - clips that still have a frame in this step (clips of different lengths batched together;
@@ -156,6 +164,11 @@ class Pipeline:
         k = self.frame_count % self.depth
         self.frame_count += 1
         S = self._det_streams[k]
+        if hasattr(frames_dev_ptr, "data_ptr"):
+            # a torch tensor: its storage is used on the slot's stream, up to `depth` steps after this call returns; tell the
+            # caching allocator, so that dropping the tensor does not hand the memory to a later batch too early
+            frames_dev_ptr.record_stream(S)
+            frames_dev_ptr = frames_dev_ptr.data_ptr()
         self._ev_in[k].record(torch.cuda.current_stream())           # frames are ready once the caller's stream gets here
         S.wait_event(self._ev_in[k])
         if self._ev_trk[k] is not None:
