@@ -184,10 +184,13 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
             }
           }
         }
-        int q[4];
+        // clamp(rne(r) + zx, lo, hi) in the float domain (exact small integers) and packed by the saturating u8
+        // conversion, like the conv epilogues (rq_pack_b): 14 instead of 23 VALU ops per four channels
+        const Rq rqsum = make_rq(a.zx, a.sum_lo, a.sum_hi);
+        float f4[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) q[e] = min(max((int)__builtin_rintf(rr[e]) + a.zx, a.sum_lo), a.sum_hi);
-        v = pack4(q[0], q[1], q[2], q[3]);
+        for (int e = 0; e < 4; e++) f4[e] = __builtin_amdgcn_fmed3f(__builtin_rintf(rr[e]), rqsum.lo_f, rqsum.hi_f) + rqsum.off;
+        v = pack4_u8f(f4[0], f4[1], f4[2], f4[3]);
       }
       *(unsigned*)(T0 + p * a.T0S + 4 * cd) = v;
     }
