@@ -102,3 +102,28 @@ def test_explicit_clamps_bit_exact(tmp_path, model_path, oracle_lib, frames):
             for tid in range(1, it.num_tensors() - 1):
                 if it.materialized(tid):
                     assert np.array_equal(it.read_tensor(tid, 2)[b], det.tensor(tid)), (flags, tid)
+
+
+def test_extreme_frames_bit_exact(model_path, oracle_lib):
+    """All-black, all-white, uniform noise and a 1-pixel checkerboard: inputs that drive many activations into the
+    saturating ends of their int8 ranges (the requantisation leaves that clamp to the u8 conversion)."""
+    from vbt_amd.interpreter import Interpreter
+    rng = np.random.Generator(np.random.PCG64(11))
+    S = 320
+    chk = ((np.add.outer(np.arange(S), np.arange(S)) & 1) * 255).astype(np.uint8)
+    frames = np.stack([np.zeros((S, S, 3), np.uint8), np.full((S, S, 3), 255, np.uint8),
+                       rng.integers(0, 256, (S, S, 3), dtype=np.uint8), np.repeat(chk[:, :, None], 3, axis=2)])
+    det = oracle_lib.OracleDetector(model_path)
+    want = [det.run(f) for f in frames]
+    tens = [[det.tensor(t) for t in range(1, det.num_tensors - 1)] for f in frames if det.run(f) is not None]
+    for flags in (8, 8 | 2048, 0):
+        it = Interpreter(model_path, max_batch=len(frames), flags=flags)
+        boxes, scores, classes, counts = it.detect(frames)
+        for b in range(len(frames)):
+            ob, os_, oc, on = want[b]
+            assert counts[b] == on and np.array_equal(scores[b], os_) and np.array_equal(boxes[b], ob), (flags, b)
+        for tid in range(1, it.num_tensors() - 1):
+            if it.materialized(tid):
+                got = it.read_tensor(tid, len(frames))
+                for b in range(len(frames)):
+                    assert np.array_equal(got[b], tens[b][tid - 1]), (flags, tid, b)
