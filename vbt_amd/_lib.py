@@ -69,10 +69,7 @@ def lib():
         # library were loaded first it would bind to /opt/rocm's copy and torch's later initialisation would
         # find "no HIP GPUs".  Importing torch first puts its runtime in the global symbol scope, and the
         # hip* symbols of libvbt_hip.so resolve to that same runtime.
-        # Pipeline keeps several HIP streams busy (one per forward in flight + the tracker); with HIP's default of 4
-        # hardware queues two of them can share a queue and serialise (measured: depth 2 39.6 k -> 54 k frames/s with 8).
-        # Only effective if the HIP runtime has not been initialised yet; never overrides the user's setting.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # (GPU_MAX_HW_QUEUES: see vbt_amd/__init__.py.)
         try:
             import torch  # noqa: F401
         except ImportError:

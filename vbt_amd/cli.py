@@ -48,7 +48,7 @@ def track(src, model, detection_treshold, df_dir, fps, frame_stride):
         st = torch.cuda.current_stream().cuda_stream
         for t in range(T):
             if frame_stride > 1 and (t + 1) % frame_stride:
-                pipe.frame_count += 1                                    # skipped frames still advance time (track.py:161-169)
+                pipe.skip_frames(1)                                      # skipped frames still advance time (track.py:161-169)
                 continue
             fd = torch.from_numpy(np.ascontiguousarray(frames[t:t + 1])).cuda()
             pipe.step(fd, st, src_hw=(H, W))

@@ -111,7 +111,8 @@ class Pipeline:
         self.interpreter = self.interpreters[0]
         self.tracker = MultiClipTracker(self.n_trk, int(max_frames) * rows_per_frame + 3 * 25, max_age=MAX_AGE,   # frames 1-3 may emit 25 rows each
                                         asso_func="diou", iou_threshold=0.1, device=device)
-        self.frame_count = 0
+        self.frame_count = 0                        # time counter of the clips: time = frame_count / fps (track.py:161,169)
+        self._step_idx = 0                          # steps enqueued so far: selects the ring slot, independent of time
         n = self.n
         self._bufs = [(torch.empty((n, 25, 4), dtype=torch.float32, device=tdev), torch.empty((n, 25), dtype=torch.float32, device=tdev),
                        torch.empty((n, 25), dtype=torch.float32, device=tdev), torch.empty((n,), dtype=torch.int32, device=tdev))
@@ -161,7 +162,10 @@ class Pipeline:
         empty slot).  With tracker_clips > n_clips a slot moves on to the next clip of its queue when one ends, so a corpus
         of ragged clips keeps the whole detector batch busy."""
         torch = self._torch
-        k = self.frame_count % self.depth
+        k = self._step_idx % self.depth
+        if k in self._pending:
+            raise RuntimeError(f"Pipeline: ring slot {k} still holds a step whose tracker update has not been enqueued")
+        self._step_idx += 1
         self.frame_count += 1
         S = self._det_streams[k]
         if hasattr(frames_dev_ptr, "data_ptr"):
@@ -202,6 +206,11 @@ class Pipeline:
         while len(self._pending) >= self.depth:                      # keep depth-1 detector steps ahead of the tracker
             self._enqueue_tracker(self._pending.pop(0))
 
+    def skip_frames(self, n=1):
+        """Frames read from the source but not processed (`frame_count % 16` of reference track.py:161-167): they advance
+        the clip time and nothing else - no ring slot is used."""
+        self.frame_count += int(n)
+
     def _drain(self):
         while self._pending:
             self._enqueue_tracker(self._pending.pop(0))
@@ -221,7 +230,7 @@ class Pipeline:
 
     def detections(self):
         """Most recent step's detector outputs (host copies) - for tests."""
-        k = (self.frame_count - 1) % self.depth
+        k = (self._step_idx - 1) % self.depth
         self._det_streams[k].synchronize()
         b, s, c, cnt = self._bufs[k]
         return b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), cnt.cpu().numpy()
