@@ -27,6 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP (see vbt_amd/__init__.py)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # The kernel plan tuned on an MI355X at B = 64 is pinned so that every run (and the committed rocprofv3 / PMC
@@ -95,6 +96,20 @@ def _cpu_name():
     return "unknown"
 
 
+def self_launch(n):
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,14 +122,16 @@ def main():
     ap.add_argument("--seed-offset", type=int, default=0, help="rehearsal: run this rank on the clips another rank would own")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, RCCL
+        # rendezvous on 127.0.0.1) BEFORE this process makes any GPU call, relay their output (rank 0 prints the JSON
+        # line) and exit with their return code.  The parent never touches the GPU and is never replaced by exec.
+        return self_launch(args.gpus)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # Rehearsal knobs (not used by the driver): VBT_BENCH_SAME_DEVICE=1 puts every rank on GPU 0 and
@@ -233,4 +250,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

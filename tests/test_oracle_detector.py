@@ -70,21 +70,24 @@ def test_single_ops_against_numpy(run, model_path):
             want = _requant(acc, c.f32(int(rec["m_off"]), C)[None, None, :], int(to["zero_point"]), int(rec["act_min"]), int(rec["act_max"]))
             assert np.array_equal(det.tensor(op.output), want)
             checked.add("dw")
-        if op.type == spec.OP_ADD and op.name == "c0.n4.sum":         # 3-input add with fused ReLU6
-            r = None
-            for j, i in enumerate(op.inputs):
-                term = (det.tensor(i).astype(np.float32) - np.float32(int(c.tensors[i]["zero_point"]))) * np.float32(rec["in_mult"][j])
-                r = term if r is None else (r.astype(np.float64) + term.astype(np.float64)).astype(np.float32)   # single rounding per fma (exact product fits)
-            want = np.clip(np.rint(r).astype(np.int64) + int(to["zero_point"]), int(rec["act_min"]), int(rec["act_max"])).astype(np.int8)
-            assert np.mean(det.tensor(op.output) == want) > 0.999      # fma vs mul+add can differ on exact rounding ties only
-            checked.add("add")
+        if op.type == spec.OP_ADD and op.name in ("c0.n4.sum.partial1", "c0.n4.sum", "b2.skip"):
+            # binary integer ADD (XNNPACK qs8-vadd): parameters re-derived from the tensor scales by the exact-rational
+            # statement of tests/test_quant_kat.py, every element by integer arithmetic
+            from test_quant_kat import ref_add_params
+            ta, tb = c.tensors[op.inputs[0]], c.tensors[op.inputs[1]]
+            prm = ref_add_params(float(ta["scale"]), float(tb["scale"]), float(to["scale"]), int(ta["zero_point"]), int(tb["zero_point"]))
+            assert tuple(int(v) for v in rec["add_q"]) == prm, op.name
+            acc = prm[0] + det.tensor(op.inputs[0]).astype(np.int64) * prm[1] + det.tensor(op.inputs[1]).astype(np.int64) * prm[2]
+            want = np.clip((acc >> prm[3]) + int(to["zero_point"]), int(rec["act_min"]), int(rec["act_max"])).astype(np.int8)
+            assert np.array_equal(det.tensor(op.output), want), op.name
+            checked.add("add:" + op.name.split(".")[-1])
         if op.type == spec.OP_RESIZE_NN and "up" in op.name and "resize" not in checked:
             x = det.tensor(op.inputs[0])
             oh = int(to["h"])
             idx = (np.arange(oh) * x.shape[0]) // oh
             assert np.array_equal(det.tensor(op.output), x[idx][:, idx])
             checked.add("resize")
-    assert checked == {"pw", "dw", "add", "resize"}
+    assert checked == {"pw", "dw", "add:partial1", "add:sum", "add:skip", "resize"}
 
 
 def test_batch_helper_equals_single(oracle_lib, model_path):

@@ -19,7 +19,8 @@ def test_lite0_op_inventory():
     from collections import Counter
     c = Counter(spec.OP_NAMES[o.type] for o in g.ops)
     assert (c["dw"], c["pw"], c["stem"]) == (80, 101, 1)
-    assert c["add"] == 24 + 9 and c["maxpool"] + c["resize"] == 24 + 2     # + 9 MBConv residual adds
+    # 24 BiFPN sums (9 of them 3-input = two chained binary ADDs, like the converter's graph) + 9 MBConv residual adds
+    assert c["add"] == 24 + 9 + 9 and c["maxpool"] + c["resize"] == 24 + 2
     stages = {st: sum(o.macs(g.tensors) for o in g.ops if o.stage == st) / 1e6 for st in ("backbone", "fpn", "head")}
     assert [round(stages[k], 1) for k in ("backbone", "fpn", "head")] == [742.5, 53.2, 68.4]
     p = {g.tensors[o.output].name: g.tensors[o.output] for o in g.ops}

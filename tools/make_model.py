@@ -28,7 +28,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-from vbt_amd import spec, synth  # noqa: E402
+from vbt_amd import quant, spec, synth  # noqa: E402
 from vbt_amd.container import (OP_DTYPE, TENSOR_DTYPE, BlobWriter, write_container)  # noqa: E402
 
 
@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--calib", type=int, default=8)
     ap.add_argument("--pos_frac", type=float, default=1e-4, help="fraction of anchors with score >= 0.5")
     ap.add_argument("--nms_score_threshold", type=float, default=1.0 / 256)
+    ap.add_argument("--tie_adds", action="store_true",
+                    help="test model: force every ADD's input/output scale ratios to exactly 0.5 or 1.0, so that the integer "
+                         "rounding of XNNPACK's qs8-vadd (half towards +infinity) is hit on about half of all elements")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -177,6 +180,36 @@ def main():
         for t in outs:
             tq[t] = qparams(lo, hi)
 
+    if args.tie_adds:
+        producer = {op.output: op for op in g.ops}
+
+        def requ(t, scale):
+            lo = min(val[t].min().item(), 0.0)
+            tq[t] = (np.float32(scale), int(np.clip(rne(-128 - lo / float(scale)), -128, 127)))
+
+        def source(t):          # the tensor whose quantisation a resize / max-pool output inherits
+            while t in producer and producer[t].type in (spec.OP_MAXPOOL, spec.OP_RESIZE_NN):
+                t = producer[t].inputs[0]
+            return t
+
+        adds = [op for op in g.ops if op.type == spec.OP_ADD]
+        fpn = [op for op in adds if op.stage == "fpn"]
+        sums = {op.output for op in fpn}
+        feats = {source(i) for op in fpn for i in op.inputs if i not in sums}
+        s_f = max(float(tq[t][0]) for t in feats)
+        for t in feats:
+            requ(t, s_f)                                     # every feature map entering a sum: one scale
+        for op in fpn:
+            requ(op.output, 2.0 * s_f)                       # partial sums: 0.5 / 0.5; final sums: 1.0 / 0.5 or 0.5 / 0.5
+        for op in adds:
+            if op.stage == "backbone":                       # ADD(project output, block input)
+                s_skip = float(tq[op.inputs[1]][0])
+                requ(op.inputs[0], s_skip / 2.0)             # 0.5 / 1.0
+                requ(op.output, s_skip)
+        for op in g.ops:
+            if op.type in (spec.OP_MAXPOOL, spec.OP_RESIZE_NN):
+                tq[op.output] = tq[op.inputs[0]]
+
     # ---- emit
     blob = BlobWriter()
     tensors = np.zeros(len(g.tensors), TENSOR_DTYPE)
@@ -204,11 +237,12 @@ def main():
             w = fw[oi].numpy().astype(np.float64)
             b = fb[oi].numpy().astype(np.float64)
             cout = w.shape[0]
-            sw = np.maximum(np.abs(w.reshape(cout, -1)).max(axis=1), 1e-9) / 127.0
+            # per-channel weight scales are float32 in a TFLite file; everything below derives from the stored values
+            sw = (np.maximum(np.abs(w.reshape(cout, -1)).max(axis=1), 1e-9) / 127.0).astype(np.float32).astype(np.float64)
             wq = np.clip(rne(w / sw.reshape(-1, 1, 1, 1)), -127, 127).astype(np.int8)
             bq = rne(b / (float(sx) * sw)).astype(np.int64)
             assert np.abs(bq).max() < 2 ** 30
-            mult = (float(sx) * sw / float(so)).astype(np.float32)
+            mult = quant.conv_requant_scales(sx, sw, so)           # XNNPACK: (s_x * s_w[c]) / s_y in float32
             if op.type == spec.OP_DW:
                 wl = np.ascontiguousarray(wq[:, 0].transpose(1, 2, 0))          # [ky][kx][C]
             elif op.type == spec.OP_STEM:
@@ -225,21 +259,17 @@ def main():
             r["b_off"] = blob.add(bq.astype("<i4"))
             r["m_off"] = blob.add(mult)
         elif op.type == spec.OP_ADD:
-            for j, i in enumerate(op.inputs):
-                r["in_mult"][j] = np.float32(float(tq[i][0]) / float(so))
+            assert len(op.inputs) == 2
+            (sa, za), (sb, zb) = tq[op.inputs[0]], tq[op.inputs[1]]
+            r["in_mult"][0], r["in_mult"][1] = np.float32(sa) / np.float32(so), np.float32(sb) / np.float32(so)
+            r["add_q"][:] = quant.xnn_qs8_add_params(sa, sb, so, za, zb)
         elif op.type == spec.OP_POSTPROCESS:
             anchors = spec.make_anchors(args.arch)
             assert anchors.shape[0] == g.num_anchors()
             r["aux_off"] = blob.add(anchors)
             sc, zc = tq[op.inputs[0]]
             sb, zb = tq[op.inputs[5]]
-            q = np.arange(-128, 128, dtype=np.float64)
-            sig = 1.0 / (1.0 + np.exp(-float(sc) * (q - zc)))
-            lq = np.clip(rne(sig * 256.0) - 128, -128, 127)         # TFLite int8 LOGISTIC: scale 1/256, zp -128
-            score_lut = ((lq + 128.0) / 256.0).astype(np.float32)
-            delta_lut = (float(sb) * (q - zb)).astype(np.float32)
-            exp_lut = np.exp(float(sb) * (q - zb)).astype(np.float32)
-            r["aux2_off"] = blob.add(np.concatenate([score_lut, delta_lut, exp_lut]))
+            r["aux2_off"] = blob.add(quant.pack_postprocess_tables(sc, zc, sb, zb))     # LOGISTIC / DEQUANTIZE / decode tables
     header = dict(arch=args.arch, image_size=S, num_anchors=g.num_anchors(), max_detections=spec.MAX_DETECTIONS,
                   nms_iou_threshold=0.5, nms_score_threshold=args.nms_score_threshold, input_tensor=0)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

@@ -3,13 +3,13 @@
 It plays the role of the reference's ``models/efficientdet_lite*.tflite`` flatbuffers
 (reference track.py:67,93; all missing from the tree, .MISSING_LARGE_BLOBS): a graph of
 int8 tensors (per-tensor scale / zero-point), conv ops with per-output-channel int8 weights,
-int32 biases and float32 requantisation multipliers, plus the anchors and look-up tables of
-the detection post-process.  The C-ABI library (csrc/vbt_model.cpp) and the C oracle
+int32 biases and float32 requantisation multipliers, binary ADDs with the integer parameters of
+XNNPACK's qs8-vadd (vbt_amd/quant.py), plus the anchors and look-up tables of the detection post-process.  The C-ABI library (csrc/vbt_model.cpp) and the C oracle
 (oracle/detector.c) each parse this file on their own; this Python module is the writer
 (tools/make_model.py) and a reader for tests.
 
 Layout (little endian):
-  header   128 B   magic "VBTM0001", ints, floats, blob offset/size
+  header   128 B   magic "VBTM0002", ints, floats, blob offset/size
   tensors  nT x 32 B   {h, w, c, zero_point, scale(f32), pad[3]}
   ops      nO x 160 B  see OP_DTYPE
   blob     raw bytes (int8 weights, int32 biases, f32 multipliers, anchors, LUTs), 16-B aligned items
@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import numpy as np
 
-MAGIC = b"VBTM0001"
+MAGIC = b"VBTM0002"   # 0002: binary integer ADD (XNNPACK qs8-vadd parameters), double-precision decode tables
 
 HEADER_DTYPE = np.dtype([
     ("magic", "S8"), ("arch", "<i4"), ("image_size", "<i4"), ("num_tensors", "<i4"), ("num_ops", "<i4"),
@@ -38,7 +38,9 @@ OP_DTYPE = np.dtype([
     ("act_min", "<i4"), ("act_max", "<i4"), ("level", "<i4"),
     ("w_off", "<i8"), ("b_off", "<i8"), ("m_off", "<i8"),       # conv: weights / bias / multipliers
     ("aux_off", "<i8"), ("aux2_off", "<i8"),                   # postprocess: anchors / LUTs
-    ("in_mult", "<f4", (3,)), ("reserved", "<i4", (5,)),
+    ("in_mult", "<f4", (3,)),                                  # ADD: s_a/s_out, s_b/s_out in float32 (informational)
+    ("add_q", "<i4", (4,)),                                    # ADD: bias, a_multiplier, b_multiplier, shift (quant.xnn_qs8_add_params)
+    ("reserved", "<i4", (1,)),
 ])
 assert OP_DTYPE.itemsize == 160, OP_DTYPE.itemsize
 

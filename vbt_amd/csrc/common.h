@@ -1,6 +1,7 @@
 // Shared host-side declarations for libvbt_hip.so (product code; never includes anything from oracle/).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -42,12 +43,43 @@ struct TensorRec {
 struct OpRec {
   int32_t type, n_inputs, inputs[12], output, k, stride, pad_t, pad_l, act_min, act_max, level;
   int64_t w_off, b_off, m_off, aux_off, aux2_off;
-  float in_mult[3];
-  int32_t reserved[5];
+  float in_mult[3];      // ADD: s_a/s_out, s_b/s_out (informational)
+  int32_t add_q[4];      // ADD: bias, a_multiplier, b_multiplier, shift (XNNPACK qs8-vadd)
+  int32_t reserved[1];
 };
 #pragma pack(pop)
 static_assert(sizeof(Header) == 128, "header");
 static_assert(sizeof(TensorRec) == 32, "tensor");
 static_assert(sizeof(OpRec) == 160, "op");
+#define VBT_CONTAINER_MAGIC "VBTM0002"
+#define VBT_POST_TABLE_BYTES (256 * 4 * 2 + 256 * 8 * 2 + 16)   // score f32 | box f32 | dq f64 | ex f64 | scales f32[4]
+
+// Integer parameters of an int8 ADD exactly as XNNPACK derives them (xnn_create_add_nd_qs8 +
+// xnn_init_qs8_add_minmax_*_params of the XNNPACK revision tflite-runtime 2.14 builds; the reference runs that kernel
+// through the default delegate, reference odt.py:58-61):  q = clamp(((bias + a*am + b*bm) >> shift) + z_out, lo, hi).
+struct AddParams { int32_t bias, am, bm, shift; };
+inline bool xnn_add_params(float s_a, float s_b, float s_out, int z_a, int z_b, AddParams* p) {
+  const float a_os = s_a / s_out, b_os = s_b / s_out;
+  if (!(a_os >= 0x1.0p-10f && a_os < 0x1.0p+8f) || !(b_os >= 0x1.0p-10f && b_os < 0x1.0p+8f)) return false;
+  const float mx = a_os > b_os ? a_os : b_os;
+  uint32_t bits;
+  memcpy(&bits, &mx, 4);
+  const int32_t max_exp = (int32_t)(bits >> 23) - 127;
+  const uint32_t shift = (uint32_t)(20 - max_exp);
+  if (shift < 12 || shift > 30) return false;
+  auto scaled = [&](float v) {  // v * 2^shift through the exponent field, then lrintf (round to nearest even)
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    b += shift << 23;
+    float f;
+    memcpy(&f, &b, 4);
+    return (int32_t)lrintf(f);
+  };
+  p->am = scaled(a_os);
+  p->bm = scaled(b_os);
+  p->shift = (int32_t)shift;
+  p->bias = (int32_t)((1u << (shift - 1)) - (uint32_t)(p->am * z_a) - (uint32_t)(p->bm * z_b));
+  return true;
+}
 
 }  // namespace vbt

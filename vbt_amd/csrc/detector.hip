@@ -1,10 +1,12 @@
 // EfficientDet-Lite int8 detector on gfx950 (MI355X): kernels + execution plan + C ABI.
 //
 // Replaces the TFLite interpreter invoke at reference odt.py:58-66 (signature_fn(images=...)).
-// Arithmetic contract (bit-exact with oracle/detector.c, which restates TFLite/XNNPACK int8):
-//   conv:  acc(int32) = sum (x_q - z_x) * w_q + bias_q ;  q = clamp(rne(float(acc) * M[c]) + z_y)
-//   add :  r = (a-z_a)*k_a ; r = fma(b-z_b, k_b, r) [; r = fma(c-z_c, k_c, r)] ; q = clamp(rne(r)+z_y)
-//   post:  table look-ups + single IEEE ops, greedy NMS in (score desc, anchor asc) order.
+// Arithmetic contract = the kernels tflite-runtime 2.14 executes on x86-64 (XNNPACK delegate by default, TFLite builtin
+// kernels for what it does not take; table in vbt_amd/quant.py), bit-exact with oracle/detector.c:
+//   conv:  acc(int32) = sum (x_q - z_x) * w_q + bias_q ;  q = clamp(rne(float(acc) * M[c]) + z_y)   (XNNPACK qs8-qc8w, fp32)
+//   add :  q = clamp(((bias + a*a_mult + b*b_mult) >> shift) + z_y), binary, integer                 (XNNPACK qs8-vadd-minmax)
+//   post:  LOGISTIC / DEQUANTIZE tables, centre-size decode in double rounded to float once per quantity, greedy NMS in
+//          (score desc, anchor asc) order                                                            (detection_postprocess.cc)
 // Design (MI355X-first):
 //   * activations int8 NHWC, batch-major [B][H][W][C]; pointwise convs run on the int8 MFMA
 //     (v_mfma_i32_16x16x32_i8) with the WEIGHTS as the A operand so every lane ends up holding 16
@@ -103,6 +105,26 @@ __device__ __forceinline__ v4i v4i_from(const int4& b) { return (v4i){b.x, b.y, 
 __device__ __forceinline__ unsigned rq_pack_i(const v4i& acc, const int4& b, const float4& mu, const Rq& q) {
   const v4i a2 = {acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w};
   return rq_pack_b(a2, mu, q);
+}
+
+// ---- int8 ADD, XNNPACK qs8-vadd-minmax: q = clamp(((bias + a*am + b*bm) >> shift) + z_out, lo, hi).  The kernel's
+// int16 / int8 saturating packs are monotone and the activation range lies inside int8, so the chain of saturations equals
+// one clamp; it is applied before the zero point is added (lo - z_out, hi - z_out), and `off` = z_out + 128 moves the
+// result to its u8 image so that four of them pack with shifts (no masks) and one XOR restores int8.
+struct AddQ { int bias, am, bm, shift, lo, hi, off; };
+static inline AddQ make_addq(const AddParams& p, int z_out, int lo, int hi) {
+  return AddQ{p.bias, p.am, p.bm, p.shift, lo - z_out, hi - z_out, z_out + 128};
+}
+__device__ __forceinline__ int addq_u8(int a, int b, const AddQ& q) {  // -> q + 128 in [0, 255]
+  const int t = (q.bias + __mul24(a, q.am) + __mul24(b, q.bm)) >> q.shift;   // |am|, |bm| < 2^22, a, b int8: 24-bit products
+  return min(max(t, q.lo), q.hi) + q.off;
+}
+__device__ __forceinline__ unsigned addq4(unsigned ua, unsigned ub, const AddQ& q) {  // four int8 lanes per dword
+  unsigned r = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    r |= (unsigned)addq_u8((int)(int8_t)(ua >> (8 * e)), (int)(int8_t)(ub >> (8 * e)), q) << (8 * e);
+  return r ^ 0x80808080u;
 }
 
 struct Epi {  // requantisation parameters of one conv
@@ -521,33 +543,18 @@ __global__ __launch_bounds__(256) void dw_col_kernel(const int8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// elementwise n-ary add with requantisation: 4 bytes per lane
+// elementwise binary int8 ADD: 16 bytes per lane
 // ------------------------------------------------------------------------------------------
-struct AddArgs {
-  const int8_t* in[3];
-  int z[3];
-  float k[3];
-  int n_in, zo, lo, hi;
-};
-__global__ __launch_bounds__(256) void add_kernel(AddArgs a, int8_t* __restrict__ out, long n4) {
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  unsigned va = ((const unsigned*)a.in[0])[i], vb = ((const unsigned*)a.in[1])[i];
-  unsigned vc = a.n_in > 2 ? ((const unsigned*)a.in[2])[i] : 0u;
-  int q[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    int xa = (int)(int8_t)(va >> (8 * j)), xb = (int)(int8_t)(vb >> (8 * j));
-    float r = (float)(xa - a.z[0]) * a.k[0];
-    r = __builtin_fmaf((float)(xb - a.z[1]), a.k[1], r);
-    if (a.n_in > 2) {
-      int xc = (int)(int8_t)(vc >> (8 * j));
-      r = __builtin_fmaf((float)(xc - a.z[2]), a.k[2], r);
-    }
-    int v = (int)__builtin_rintf(r) + a.zo;
-    q[j] = min(max(v, a.lo), a.hi);
+__global__ __launch_bounds__(256) void add_kernel(const int8_t* __restrict__ xa, const int8_t* __restrict__ xb, AddQ q,
+                                                  int8_t* __restrict__ out, long n4) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool al16 = ((((unsigned long)xa) | ((unsigned long)xb) | ((unsigned long)out)) & 15ul) == 0;   // (sub-batch offsets may break it)
+  if (al16 && i + 4 <= n4) {
+    const uint4 va = *(const uint4*)(xa + 4 * i), vb = *(const uint4*)(xb + 4 * i);
+    *(uint4*)(out + 4 * i) = make_uint4(addq4(va.x, vb.x, q), addq4(va.y, vb.y, q), addq4(va.z, vb.z, q), addq4(va.w, vb.w, q));
+  } else {
+    for (long e = i + 4; i < n4 && i < e; i++) ((unsigned*)out)[i] = addq4(((const unsigned*)xa)[i], ((const unsigned*)xb)[i], q);
   }
-  ((unsigned*)out)[i] = pack4(q[0], q[1], q[2], q[3]);
 }
 
 __device__ __forceinline__ unsigned max4_s8(unsigned a, unsigned b) {
@@ -609,7 +616,7 @@ struct PostArgs {
   const int8_t* box[5];
   int base[6];         // first anchor index of each level, base[5] = A
   const float* anchors;  // [A][4] ycenter, xcenter, h, w
-  const float* luts;     // score[256], delta[256], exp[256]
+  const unsigned char* tables;  // score f32[256] | box f32[256] | dq f64[256] | ex f64[256] | scales f32[4] (vbt_amd/quant.py)
   int A, max_det, qmin;  // qmin: lowest int8 class value whose score >= nms_score_threshold (128 = none)
   float iou_thr;
 };
@@ -629,7 +636,8 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
                                                           float* __restrict__ classes, int* __restrict__ counts) {
   __shared__ int hist[256];
   __shared__ unsigned keys[POST_CAP];
-  __shared__ float lut[768];
+  __shared__ float s_score[256];            // dequantised LOGISTIC output per class byte
+  __shared__ double s_dq[256], s_ex[256];   // (double)box / y_scale and exp((double)box / h_scale) per box byte
   __shared__ float4 selbox[VBT_MAX_DETECTIONS + 7];
   __shared__ int s_n, s_qlo, s_qhi, s_i0, s_i1, s_nsel, s_done;
   const int tid = threadIdx.x;
@@ -643,7 +651,9 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
     box[l] = p.box[l] + b * (long)nl * 4;
   }
   hist[tid] = 0;
-  for (int i = tid; i < 768; i += 256) lut[i] = p.luts[i];
+  s_score[tid] = ((const float*)p.tables)[tid];
+  s_dq[tid] = ((const double*)(p.tables + 2048))[tid];
+  s_ex[tid] = ((const double*)(p.tables + 4096))[tid];
   if (tid == 0) { s_nsel = 0; s_done = 0; }
   __syncthreads();
   // pass 1: histogram of the class bytes
@@ -752,12 +762,14 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
           for (int t = 1; t < 5; t++) l += (a >= p.base[t]) ? 1 : 0;
           unsigned bq = *(const unsigned*)(box[l] + (long)(a - p.base[l]) * 4);
           float4 an = *(const float4*)(p.anchors + (long)a * 4);
-          float yc = __builtin_fmaf(lut[256 + (int)((bq & 255u) ^ 128u)], an.z, an.x);
-          float xc = __builtin_fmaf(lut[256 + (int)(((bq >> 8) & 255u) ^ 128u)], an.w, an.y);
-          float hh = (0.5f * lut[512 + (int)(((bq >> 16) & 255u) ^ 128u)]) * an.z;
-          float hw = (0.5f * lut[512 + (int)((bq >> 24) ^ 128u)]) * an.w;
+          // DecodeCenterSizeBoxes (detection_postprocess.cc): double intermediates (one mul, one add: no contraction),
+          // one rounding to float per quantity, then float corner arithmetic
+          float yc = (float)(s_dq[(int)((bq & 255u) ^ 128u)] * (double)an.z + (double)an.x);
+          float xc = (float)(s_dq[(int)(((bq >> 8) & 255u) ^ 128u)] * (double)an.w + (double)an.y);
+          float hh = (float)(0.5 * s_ex[(int)(((bq >> 16) & 255u) ^ 128u)] * (double)an.z);
+          float hw = (float)(0.5 * s_ex[(int)((bq >> 24) ^ 128u)] * (double)an.w);
           bx = make_float4(yc - hh, xc - hw, yc + hh, xc + hw);
-          sc = lut[q + 128];
+          sc = s_score[q + 128];
           for (int s = 0; s < nsel; s++)
             if (iou_box(selbox[s], bx) > p.iou_thr) { alive = false; break; }
         }
@@ -852,6 +864,7 @@ struct Step {
   int* bias = nullptr;     // folded bias (device, padded)
   float* mult = nullptr;   // multipliers (device, padded)
   int KS = 0, NB = 0;
+  AddQ addq = {0, 0, 0, 0, 0, 0, 0};   // F_ADD: XNNPACK qs8-vadd parameters, derived from the tensor scales
   double alg_bytes_per_frame = 0, weight_bytes = 0, macs_per_frame = 0;
   // fused block (F_MBCONV / F_SEPCONV): constituent op indices (-1 = absent) and kernel arguments
   int e_op = -1, d_op = -1, p_op = -1, a_op = -1;
@@ -901,7 +914,7 @@ struct vbt_model {
   float* out_classes = nullptr;
   int* out_counts = nullptr;
   float* d_anchors = nullptr;
-  float* d_luts = nullptr;
+  unsigned char* d_luts = nullptr;   // post-process tables (see PostArgs)
   std::vector<Step> steps;      // execution list (after fusion + autotuning)
   std::vector<Group> groups;
   std::vector<Step> op_steps;   // one per graph op (weights live here)
@@ -1097,30 +1110,23 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     a.zo = tout.zero_point; a.lop = pop.act_min; a.hip = pop.act_max;
     a.rqp = make_rq(a.zo, a.lop, a.hip);
   }
-  if (a_op >= 0) {
-    const OpRec& aop = m->ops[a_op];
-    const TensorRec& tr = m->tensors[aop.output];
-    a.has_res = 1; a.ka = aop.in_mult[0]; a.kb = aop.in_mult[1];
-    a.zr = tr.zero_point; a.lor = aop.act_min; a.hir = aop.act_max;
+  if (a_op >= 0) {   // fuse_plan guarantees inputs = (project output, block input)
+    a.has_res = 1;
+    a.resq = m->op_steps[a_op].addq;
   }
   if (sum_op >= 0) {
-    const OpRec& sop = m->ops[sum_op];
     a.n_src = ns->n;
     for (int j = 0; j < ns->n; j++) {
       const TensorRec& ts = m->tensors[ns->tensor[j]];
       s.src_tensor[j] = ns->tensor[j];
       a.sh[j] = ts.h; a.sw[j] = ts.w; a.smode[j] = ns->mode[j];
-      a.sz[j] = ts.zero_point; a.sk[j] = sop.in_mult[j];
       if (ns->mode[j] == 2) { a.spt[j] = m->ops[ns->rs_op[j]].pad_t; a.spl[j] = m->ops[ns->rs_op[j]].pad_l; }
     }
-    a.sum_lo = sop.act_min; a.sum_hi = sop.act_max;
+    a.sumq = m->op_steps[sum_op].addq;   // resize / max-pool outputs keep their input's quantisation, so the parameters hold for the absorbed sources
+    a.chain = 0;
     if (ns->pre_add >= 0) {   // two chained binary ADDs
-      const OpRec& pre = m->ops[ns->pre_add];
-      const TensorRec& tp = m->tensors[pre.output];
       a.chain = ns->chain;
-      a.sk[0] = pre.in_mult[0]; a.sk[1] = pre.in_mult[1]; a.sk[2] = 0.0f;
-      a.cz = tp.zero_point; a.clo = pre.act_min; a.chi = pre.act_max;
-      a.ck[0] = sop.in_mult[0]; a.ck[1] = sop.in_mult[1];
+      a.preq = m->op_steps[ns->pre_add].addq;
     }
   }
   s.nbp = ps.NB <= 3 ? ps.NB : 5;
@@ -1446,14 +1452,15 @@ static int fuse_plan(vbt_model* m) {
   if (fuse_node)
     for (int i = 0; i < no; i++) {
       const OpRec& ad = m->ops[i];
-      if (ad.type != OP_ADD || ad.n_inputs < 2 || ad.n_inputs > 3 || !sep_ok(i + 1) || m->ops[i + 1].inputs[0] != ad.output ||
+      if (ad.type != OP_ADD || ad.n_inputs != 2 || !sep_ok(i + 1) || m->ops[i + 1].inputs[0] != ad.output ||
           consumers[ad.output] != 1 || m->tensors[ad.output].c % 4 != 0)
         continue;
       NodeSrc ns;
       auto absorb = [&](int j, int t) {   // source j = tensor t, read through the resize / max pool that produced it when possible
         const int pj = producer[t];
         ns.tensor[j] = t; ns.mode[j] = 0; ns.rs_op[j] = -1;
-        if (pj >= 0 && consumers[t] == 1 && (m->ops[pj].type == OP_RESIZE_NN || (m->ops[pj].type == OP_MAXPOOL && m->ops[pj].k == 3 && m->ops[pj].stride == 2))) {
+        const bool same_q = pj >= 0 && m->tensors[m->ops[pj].inputs[0]].scale == m->tensors[t].scale && m->tensors[m->ops[pj].inputs[0]].zero_point == m->tensors[t].zero_point;
+        if (pj >= 0 && same_q && consumers[t] == 1 && (m->ops[pj].type == OP_RESIZE_NN || (m->ops[pj].type == OP_MAXPOOL && m->ops[pj].k == 3 && m->ops[pj].stride == 2))) {
           ns.tensor[j] = m->ops[pj].inputs[0];
           ns.mode[j] = m->ops[pj].type == OP_RESIZE_NN ? 1 : 2;
           ns.rs_op[j] = pj;
@@ -1629,7 +1636,7 @@ static int chain_nodes(vbt_model* m) {
     const Step& st = fa.steps[0];
     const OpRec& d = m->ops[st.d_op];
     const int HW = st.fa.H * st.fa.W, NB = (st.fa.Cout + 63) / 64;
-    return st.fa.chain == 0 && d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= 400 &&
+    return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= 400 &&
            ((HW + 15) / 16) * NB <= NC_WAVES * NC_MAXU && st.fa.Cin % 4 == 0;
   };
   auto outputs_of = [&](const Group& g, std::set<int>& acc) {
@@ -1810,13 +1817,52 @@ static int build_plan(vbt_model* m) {
       }
     } else if (op.type == OP_ADD) {
       s.family = F_ADD;
-      if (((long)to.h * to.w * to.c) % 4 != 0 || op.n_inputs < 2 || op.n_inputs > 3) { set_error("unsupported add"); return VBT_ERR_ARG; }
+      if (((long)to.h * to.w * to.c) % 4 != 0 || op.n_inputs != 2) { set_error("unsupported add (binary int8 ADD on a multiple of 4 elements expected)"); return VBT_ERR_ARG; }
+      const TensorRec& ta = m->tensors[op.inputs[0]];
+      const TensorRec& tb = m->tensors[op.inputs[1]];
+      AddParams ap;
+      if (!xnn_add_params(ta.scale, tb.scale, to.scale, ta.zero_point, tb.zero_point, &ap)) {
+        set_error("op %d: ADD input/output scale ratio outside [2^-10, 2^8) (XNNPACK refuses it too)", oi);
+        return VBT_ERR_ARG;
+      }
+      if (ap.bias != op.add_q[0] || ap.am != op.add_q[1] || ap.bm != op.add_q[2] || ap.shift != op.add_q[3]) {
+        set_error("op %d: ADD parameters stored in the container (%d,%d,%d,%d) differ from those derived from the tensor scales (%d,%d,%d,%d)",
+                  oi, op.add_q[0], op.add_q[1], op.add_q[2], op.add_q[3], ap.bias, ap.am, ap.bm, ap.shift);
+        return VBT_ERR_ARG;
+      }
+      s.addq = make_addq(ap, to.zero_point, op.act_min, op.act_max);
+      // survey accounting: a 3-input BiFPN sum is one add; the partial sum between its two binary ADDs is not traffic
+      auto sole_add_consumer = [&](int t) {
+        int n = 0, add = 0;
+        for (const OpRec& o2 : m->ops)
+          for (int i = 0; i < o2.n_inputs; i++)
+            if (o2.inputs[i] == t) { n++; add += o2.type == OP_ADD; }
+        return n == 1 && add == 1;
+      };
+      if (sole_add_consumer(op.output)) s.alg_bytes_per_frame -= out_el;
+      for (int i = 0; i < 2; i++) {
+        bool from_add = false;
+        for (int o2 = 0; o2 < oi; o2++) from_add |= m->ops[o2].type == OP_ADD && m->ops[o2].output == op.inputs[i];
+        if (from_add && sole_add_consumer(op.inputs[i])) s.alg_bytes_per_frame -= (double)m->tensors[op.inputs[i]].h * m->tensors[op.inputs[i]].w * m->tensors[op.inputs[i]].c;
+      }
     } else if (op.type == OP_MAXPOOL) {
       s.family = F_MAXPOOL;
       if (to.c % 4 != 0 || op.k != 3 || op.stride != 2) { set_error("unsupported maxpool"); return VBT_ERR_ARG; }
     } else if (op.type == OP_RESIZE_NN) {
       s.family = F_RESIZE;
       if (to.c % 4 != 0) { set_error("unsupported resize"); return VBT_ERR_ARG; }
+      // TFLite's kernel computes src = min(floor(dst * (float)in / out), in - 1) in float32; the kernels here use the
+      // integer form floor(dst * in / out): refuse a geometry on which the two differ
+      const TensorRec& ti = m->tensors[op.inputs[0]];
+      for (int ax = 0; ax < 2; ax++) {
+        const int in = ax ? ti.w : ti.h, out = ax ? to.w : to.h;
+        const float scale = (float)in / (float)out;
+        for (int d = 0; d < out; d++)
+          if (std::min((int)floorf((float)d * scale), in - 1) != (d * in) / out) {
+            set_error("op %d: nearest-neighbour resize %d -> %d is not mapped", oi, in, out);
+            return VBT_ERR_ARG;
+          }
+      }
     } else if (op.type == OP_POSTPROCESS) {
       s.family = F_POST;
       if (op.n_inputs != 10 || m->hdr.max_detections != VBT_MAX_DETECTIONS || m->hdr.num_anchors > 65535) {
@@ -1993,17 +2039,8 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       break;
     }
     case F_ADD: {
-      AddArgs a;
-      a.n_in = op.n_inputs;
-      for (int i = 0; i < 3; i++) {
-        int ii = i < op.n_inputs ? i : 0;
-        a.in[i] = TP(op.inputs[ii]);
-        a.z[i] = m->tensors[op.inputs[ii]].zero_point;
-        a.k[i] = op.in_mult[ii];
-      }
-      a.zo = to.zero_point; a.lo = op.act_min; a.hi = op.act_max;
       long n4 = (long)B * to.h * to.w * to.c / 4;
-      add_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(a, out, n4);
+      add_kernel<<<dim3((unsigned)((n4 + 1023) / 1024)), 256, 0, st>>>(TP(op.inputs[0]), TP(op.inputs[1]), s.addq, out, n4);
       break;
     }
     case F_MAXPOOL: {
@@ -2168,7 +2205,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       }
       p.base[5] = base;
       p.anchors = m->d_anchors;
-      p.luts = m->d_luts;
+      p.tables = m->d_luts;
       p.A = m->hdr.num_anchors;
       p.max_det = m->hdr.max_detections;
       p.iou_thr = m->hdr.nms_iou_threshold;
@@ -2429,7 +2466,7 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
   FILE* f = fopen(path, "rb");
   if (!f) { set_error("cannot open model container '%s'", path); return VBT_ERR_IO; }
   vbt_model* m = new vbt_model();
-  bool ok = fread(&m->hdr, sizeof(Header), 1, f) == 1 && memcmp(m->hdr.magic, "VBTM0001", 8) == 0;
+  bool ok = fread(&m->hdr, sizeof(Header), 1, f) == 1 && memcmp(m->hdr.magic, VBT_CONTAINER_MAGIC, 8) == 0;
   if (ok) {
     m->tensors.resize(m->hdr.num_tensors);
     m->ops.resize(m->hdr.num_ops);
@@ -2440,7 +2477,7 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
          fread(m->blob.data(), 1, m->blob.size(), f) == m->blob.size();
   }
   fclose(f);
-  if (!ok) { delete m; set_error("'%s' is not a valid VBTM container", path); return VBT_ERR_IO; }
+  if (!ok) { delete m; set_error("'%s' is not a valid " VBT_CONTAINER_MAGIC " container (older containers: regenerate with tools/make_model.py)", path); return VBT_ERR_IO; }
   m->device = device;
   m->max_batch = max_batch;
   m->flags = flags;
@@ -2480,7 +2517,10 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
   for (const OpRec& op : m->ops)
     if (op.type == OP_POSTPROCESS) {
       std::vector<float> an((const float*)(m->blob.data() + op.aux_off), (const float*)(m->blob.data() + op.aux_off) + (size_t)m->hdr.num_anchors * 4);
-      std::vector<float> lut((const float*)(m->blob.data() + op.aux2_off), (const float*)(m->blob.data() + op.aux2_off) + 768);
+      if ((size_t)op.aux2_off + VBT_POST_TABLE_BYTES > m->blob.size()) { set_error("post-process tables truncated"); return fail(VBT_ERR_IO); }
+      std::vector<unsigned char> lut(m->blob.data() + op.aux2_off, m->blob.data() + op.aux2_off + VBT_POST_TABLE_BYTES);
+      const float* sv = (const float*)(lut.data() + 6144);
+      if (sv[0] != sv[1] || sv[2] != sv[3]) { set_error("post-process: y_scale != x_scale or h_scale != w_scale"); return fail(VBT_ERR_ARG); }
       if ((rc = upload(m, an, &m->d_anchors)) || (rc = upload(m, lut, &m->d_luts))) return fail(rc);
     }
   {

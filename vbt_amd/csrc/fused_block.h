@@ -53,22 +53,26 @@ struct FusedArgs {
   const float* mp;
   int KSp, zo, lop, hip;
   Rq rqp;
-  // residual ADD (out = clamp(rne((q - zo)*ka + (x - zx)*kb) + zr))
+  // residual ADD: out = ADD(project output, block input), the graph's input order (AddQ: XNNPACK qs8-vadd, detector.hip)
   int has_res;
-  float ka, kb;
-  int zr, lor, hir;
-  // BiFPN node: the tile is the n-ary ADD (+ReLU6) of up to three sources, each read through a
-  // resampling map (0 identity, 1 nearest-neighbour up: src = floor(dst*in/out), 2 max-pool 3x3/2 SAME)
+  AddQ resq;
+  // BiFPN node: the tile is the sum (+ReLU6) of two or three sources, each read through a resampling map
+  // (0 identity, 1 nearest-neighbour up: src = floor(dst*in/out), 2 max-pool 3x3/2 SAME).  ADD is binary:
+  //   n_src == 2: tile = ADD(src0, src1; sumq)
+  //   n_src == 3: p = ADD(src0, src1; preq) - the partial sum with its own quantisation - then
+  //               tile = ADD(p, src2; sumq) (chain == 1) or ADD(src2, p; sumq) (chain == 2)
   int n_src;
   const int8_t* src[3];
-  int sh[3], sw[3], smode[3], spt[3], spl[3], sz[3];
-  float sk[3];
-  int sum_lo, sum_hi;  // clamp of the sum (its zero point is zx)
-  // chained binary ADDs (a 3-input sum of a TFLite graph): p = requant(src0, src1) with its own quantisation (cz, clo, chi),
-  // then the tile = requant(p, src2) (chain == 1) or requant(src2, p) (chain == 2) with multipliers ck[0], ck[1] in that order
-  int chain, cz, clo, chi;
-  float ck[2];
+  int sh[3], sw[3], smode[3], spt[3], spl[3];
+  int chain;
+  AddQ sumq, preq;
 };
+
+__device__ __forceinline__ unsigned node_sum4(const unsigned u[3], const FusedArgs& a) {
+  if (a.chain == 0) return addq4(u[0], u[1], a.sumq);
+  const unsigned p = addq4(u[0], u[1], a.preq);
+  return a.chain == 1 ? addq4(p, u[2], a.sumq) : addq4(u[2], p, a.sumq);
+}
 
 // two unsigned 16-bit maxima in one VALU op (v_pk_max_u16)
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
@@ -110,7 +114,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   bool summed = false;
   if constexpr (!EXPAND) summed = a.n_src > 0;
   if (summed) {
-    // BiFPN node input: resample + n-ary add + clamp, 4 channels per lane-iteration (same float ops as add_kernel)
+    // BiFPN node input: resample + binary integer ADD(s) + clamp, 4 channels per lane-iteration (same arithmetic as add_kernel)
     const int nd = a.Cin >> 2;
     const unsigned zb4 = (unsigned)(a.zx & 255) * 0x01010101u;
     const int pstep = 256 / nd;                       // pixels advanced per round (planner guarantees nd <= 256)
@@ -124,7 +128,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       while (hx >= HWx) { hx -= HWx; hy++; }
       unsigned v = zb4;
       if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned us[3] = {0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           if (j < a.n_src) {
@@ -163,34 +167,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
               }
               u = (lo | (hi << 8)) ^ 0x80808080u;
             }
-            // (q - z) as float: v_cvt_f32_ubyteN of the u8 image (q + 128) minus (128 + z), both exact
-            const unsigned ub = u ^ 0x80808080u;
-            const float zf = (float)(128 + a.sz[j]);
-            if (a.chain && j == 2) {
-              // third source of a chained sum: first requantise the partial sum of sources 0 and 1, then add in ADD order
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const int q1 = min(max((int)__builtin_rintf(rr[e]) + a.cz, a.clo), a.chi);
-                const float fp = (float)(q1 - a.cz);
-                const float fc = (float)((ub >> (8 * e)) & 255u) - zf;
-                rr[e] = a.chain == 1 ? __builtin_fmaf(fc, a.ck[1], fp * a.ck[0]) : __builtin_fmaf(fp, a.ck[1], fc * a.ck[0]);
-              }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                float f = (float)((ub >> (8 * e)) & 255u) - zf;
-                rr[e] = j == 0 ? f * a.sk[0] : __builtin_fmaf(f, a.sk[j], rr[e]);
-              }
-            }
+            us[j] = u;
           }
         }
-        // clamp(rne(r) + zx, lo, hi) in the float domain (exact small integers) and packed by the saturating u8
-        // conversion, like the conv epilogues (rq_pack_b): 14 instead of 23 VALU ops per four channels
-        const Rq rqsum = make_rq(a.zx, a.sum_lo, a.sum_hi);
-        float f4[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) f4[e] = __builtin_amdgcn_fmed3f(__builtin_rintf(rr[e]), rqsum.lo_f, rqsum.hi_f) + rqsum.off;
-        v = pack4_u8f(f4[0], f4[1], f4[2], f4[3]);
+        v = node_sum4(us, a);   // binary integer ADDs (+ fused ReLU6 clamp), exactly the standalone add_kernel arithmetic
       }
       *(unsigned*)(T0 + p * a.T0S + 4 * cd) = v;
     }
@@ -488,18 +468,11 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
         int4 bb = *(const int4*)(a.bp + c0 + 4 * t);
         float4 mu = *(const float4*)(a.mp + c0 + 4 * t);
         unsigned dq = rq_pack_i(acc[nb][t], bb, mu, a.rqp);
-        int q[4] = {(int)(int8_t)(dq & 255u), (int)(int8_t)((dq >> 8) & 255u), (int)(int8_t)((dq >> 16) & 255u), (int)(int8_t)(dq >> 24)};
-        if (a.has_res) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            int xs = (int)(int8_t)skip[min(c0 + 4 * t + j, a.Cin - 1)];
-            float rr = (float)(q[j] - a.zo) * a.ka;
-            rr = __builtin_fmaf((float)(xs - a.zx), a.kb, rr);
-            int v = (int)__builtin_rintf(rr) + a.zr;
-            q[j] = min(max(v, a.lor), a.hir);
-          }
+        if (a.has_res) {   // Cin == Cout, a multiple of 8: the skip dword is in range whenever c0 + 4t < Cout
+          const unsigned xs = *(const unsigned*)(skip + min(c0 + 4 * t, a.Cin - 4));
+          dq = addq4(dq, xs, a.resq);
         }
-        d[t] = a.has_res ? pack4(q[0], q[1], q[2], q[3]) : dq;
+        d[t] = dq;
       }
       int8_t* o = orow + c0;
       if ((a.Cout & 15) == 0) {

@@ -162,19 +162,7 @@ __global__ __launch_bounds__(IB_THREADS) void mbconv_image_kernel(FusedArgs a, I
       const int4 bb = *(const int4*)(a.bp + c0 + 4 * t);
       const float4 mu = *(const float4*)(a.mp + c0 + 4 * t);
       const unsigned dq = rq_pack_i(acc[i][t], bb, mu, a.rqp);
-      if (a.has_res) {
-        int q[4] = {(int)(int8_t)(dq & 255u), (int)(int8_t)((dq >> 8) & 255u), (int)(int8_t)((dq >> 16) & 255u), (int)(int8_t)(dq >> 24)};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int xs = (int)(int8_t)skip[min(c0 + 4 * t + j, a.Cin - 1)];
-          float rr = (float)(q[j] - a.zo) * a.ka;
-          rr = __builtin_fmaf((float)(xs - a.zx), a.kb, rr);
-          q[j] = min(max((int)__builtin_rintf(rr) + a.zr, a.lor), a.hir);
-        }
-        d[t] = pack4(q[0], q[1], q[2], q[3]);
-      } else {
-        d[t] = dq;
-      }
+      d[t] = a.has_res ? addq4(dq, *(const unsigned*)(skip + min(c0 + 4 * t, a.Cin - 4)), a.resq) : dq;
     }
     int8_t* o = a.out + (b * OHW + slot) * (long)a.Cout + c0;
     if ((a.Cout & 15) == 0) {

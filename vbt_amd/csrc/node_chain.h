@@ -24,7 +24,7 @@ __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs*
     unsigned char* T = nc_smem;
     unsigned char* D = T + PH * PW * TS;
     const float rcp_w = 1.0f / (float)W;
-    // ---- sum stage: T interior <- clamp(rne(sum_j (src_j - z_j) * k_j) + zx), border <- zx; 4 channels per lane-iteration ----
+    // ---- sum stage: T interior <- binary integer ADD(s) of the resampled sources (node_sum4), border <- zx; 4 channels per lane-iteration ----
     {
       const int nd = C >> 2, ndp = TS >> 2;                // dwords per pixel: real channels / whole LDS row
       const unsigned zb4 = (unsigned)(a.zx & 255) * 0x01010101u;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs*
         const int iy = py - 1, ix = px - 1;
         unsigned v = zb4;
         if (cd < nd && iy >= 0 && iy < H && ix >= 0 && ix < W) {
-          float rr[4] = {0.f, 0.f, 0.f, 0.f};
+          unsigned us[3] = {0u, 0u, 0u};
 #pragma unroll
           for (int j = 0; j < 3; j++) {
             if (j < a.n_src) {
@@ -63,17 +63,10 @@ __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs*
                 }
                 u = pack4(m0, m1, m2, m3);
               }
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const float f = (float)((int)(int8_t)(u >> (8 * e)) - a.sz[j]);
-                rr[e] = j == 0 ? f * a.sk[0] : __builtin_fmaf(f, a.sk[j], rr[e]);
-              }
+              us[j] = u;
             }
           }
-          int q[4];
-#pragma unroll
-          for (int e = 0; e < 4; e++) q[e] = min(max((int)__builtin_rintf(rr[e]) + a.zx, a.sum_lo), a.sum_hi);
-          v = pack4(q[0], q[1], q[2], q[3]);
+          v = node_sum4(us, a);
         }
         *(unsigned*)(T + p * TS + 4 * cd) = v;
       }

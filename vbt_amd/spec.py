@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 OP_STEM = 1       # 3x3 stride-2 conv on the uint8 frame (Cin = 3)
 OP_PW = 2         # 1x1 conv
 OP_DW = 3         # depthwise kxk conv
-OP_ADD = 4        # n-ary (2|3) elementwise add with requantisation
+OP_ADD = 4        # binary elementwise int8 ADD (TFLite ADD / XNNPACK qs8-vadd); 3-input BiFPN sums are two chained ADDs
 OP_MAXPOOL = 5    # 3x3 stride-2 SAME max pool
 OP_RESIZE_NN = 6  # nearest-neighbour resize (legacy TF semantics: src = floor(dst*in/out))
 OP_POSTPROCESS = 7
@@ -159,12 +159,20 @@ class Graph:
                            stage=stage, level=level, share=share))
 
     def addn(self, name, xs, act, stage):
+        """Sum of 2 or 3 tensors as the Keras EfficientDet writes it (`sum(nodes)`: ((n0 + n1) + n2)) and the TFLite
+        converter keeps it: binary ADD ops, the partial sum with a quantisation of its own and no activation, the
+        activation fused into the last ADD."""
         t = self.tensors[xs[0]]
         for x in xs[1:]:
             u = self.tensors[x]
             assert (u.h, u.w, u.c) == (t.h, t.w, t.c), (name, t, u)
-        o = self.tensor(name, t.h, t.w, t.c)
-        return self.add(Op(OP_ADD, name, list(xs), o, act=act, stage=stage))
+        assert 2 <= len(xs) <= 3
+        acc = xs[0]
+        for j, x in enumerate(xs[1:], 1):
+            last = j == len(xs) - 1
+            o = self.tensor(name if last else f"{name}.partial{j}", t.h, t.w, t.c)
+            acc = self.add(Op(OP_ADD, name if last else f"{name}.partial{j}", [acc, x], o, act=act if last else ACT_NONE, stage=stage))
+        return acc
 
     def maxpool(self, name, x, stage):
         t = self.tensors[x]
@@ -185,12 +193,16 @@ class Graph:
     def activation_elems(self) -> int:
         """Compulsory activation traffic: every op reads its inputs once and writes its
         output once."""
-        n = 0
-        for op in self.ops:
-            if op.type == OP_POSTPROCESS:
-                continue
-            n += sum(self.tensors[i].elems for i in op.inputs) + self.tensors[op.output].elems
-        return n
+        return sum(self.alg_elems(op) for op in self.ops)
+
+    def alg_elems(self, op) -> int:
+        """Activation elements an op moves in the survey's accounting.  A 3-input BiFPN sum is ONE add there (three
+        reads, one write): the partial sum between its two binary ADDs is not counted on either side."""
+        if op.type == OP_POSTPROCESS:
+            return 0
+        partial = lambda t: self.tensors[t].name.rsplit(".", 1)[-1].startswith("partial")
+        n = sum(self.tensors[i].elems for i in op.inputs if not partial(i))
+        return n + (0 if partial(op.output) else self.tensors[op.output].elems)
 
     def weight_elems(self) -> int:
         seen = set()
@@ -332,7 +344,7 @@ def per_op_bytes(g: Graph, act_bytes: int = 1, w_bytes: int = 1, batch: int = 1)
     for op in g.ops:
         if op.type == OP_POSTPROCESS:
             continue
-        a = sum(g.tensors[i].elems for i in op.inputs) + g.tensors[op.output].elems
+        a = g.alg_elems(op)
         w = op.weight_elems(g.tensors)
         rows.append((op.name, OP_NAMES[op.type], a * act_bytes * batch + w * w_bytes, op.macs(g.tensors) * batch))
     return rows

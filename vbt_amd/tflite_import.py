@@ -25,7 +25,7 @@ import tempfile
 
 import numpy as np
 
-from . import spec
+from . import quant, spec
 from .container import OP_DTYPE, TENSOR_DTYPE, BlobWriter, write_container
 from .flatbuf import Table, flex_root
 
@@ -289,7 +289,7 @@ def import_tflite(path):
             if b_t.type != TT_INT32 or not b_t.is_const or b_t.data.size != cout:
                 raise UnsupportedModel(f"{where}: constant int32 bias expected")
             bias = np.asarray(b_t.data, "<i4").reshape(-1)
-        mult = ((np.float32(sx) * sw) / np.float32(so)).astype(np.float32)
+        mult = quant.conv_requant_scales(sx, sw, so)        # XNNPACK: (s_x * s_w[c]) / s_y in float32
         return bias, mult
 
     in_container = None
@@ -367,8 +367,12 @@ def import_tflite(path):
             so, zo = T[op.outputs[0]].q()
             o = new_tensor(op.outputs[0])
             r = new_op(spec.OP_ADD, ins, o, act=_act_range(op.opt(0, "b"), so, zo, where))   # AddOptions.fused_activation_function:0
-            for j, xi in enumerate(ins):
-                r["in_mult"][j] = np.float32(np.float32(tensors[xi][4]) / np.float32(so))
+            (sa, za), (sb, zb) = (tensors[ins[0]][4], tensors[ins[0]][3]), (tensors[ins[1]][4], tensors[ins[1]][3])
+            r["in_mult"][0], r["in_mult"][1] = np.float32(sa) / np.float32(so), np.float32(sb) / np.float32(so)
+            try:
+                r["add_q"][:] = quant.xnn_qs8_add_params(sa, sb, so, za, zb)     # XNNPACK qs8-vadd-minmax, integer
+            except ValueError as e:
+                raise UnsupportedModel(f"{where}: {e}")
             continue
         if op.code == BO_MAX_POOL_2D:
             pad, sw_, sh_ = op.opt(0, "b"), op.opt(1, "i", 1), op.opt(2, "i", 1)      # Pool2DOptions 0,1,2
@@ -428,19 +432,17 @@ def import_tflite(path):
     tensors.append((1, spec.MAX_DETECTIONS, 6, 0, np.float32(1.0)))
     r = new_op(spec.OP_POSTPROCESS, [tmap[t] for t in cls_levels] + [tmap[t] for t in box_levels], det)
     r["aux_off"] = blob.add(anchors)
-    q = np.arange(-128, 128, dtype=np.float64)
     sc, zc = cls_q
     sb, zb = box_q
-    if cls_log is not None:
-        so, zo = T[cls_log].q()
-        sig = 1.0 / (1.0 + np.exp(-float(sc) * (q - zc)))
-        lq = np.clip(np.rint(sig / float(so)) + zo, -128, 127)
-        score_lut = (float(so) * (lq - zo)).astype(np.float32)
-    else:
-        score_lut = (float(sc) * (q - zc)).astype(np.float32)
-    delta_lut = (float(sb) * (q - zb) / y_scale).astype(np.float32)
-    exp_lut = np.exp(float(sb) * (q - zb) / h_scale).astype(np.float32)
-    r["aux2_off"] = blob.add(np.concatenate([score_lut, delta_lut, exp_lut]))
+    if cls_log is None:
+        raise UnsupportedModel("class branch without LOGISTIC: raw logits as scores are not mapped")
+    so, zo = T[cls_log].q()
+    try:
+        # LOGISTIC (XNNPACK x8-lut), DEQUANTIZE and the double-precision decode tables of detection_postprocess.cc
+        r["aux2_off"] = blob.add(quant.pack_postprocess_tables(sc, zc, sb, zb, y_scale=y_scale, h_scale=h_scale))
+        quant.xnn_qs8_sigmoid_lut(sc, zc, so, zo)
+    except ValueError as e:
+        raise UnsupportedModel(f"{POSTPROCESS_NAME}: {e}")
 
     tarr = np.zeros(len(tensors), TENSOR_DTYPE)
     for i, (h, w, c, z, s) in enumerate(tensors):
