@@ -33,7 +33,7 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROAR
 # The kernel plan tuned on an MI355X at B = 64 is pinned so that every run (and the committed rocprofv3 / PMC
 # summaries under profiles/) executes the same kernels; a different batch size or missing file re-tunes.
 os.environ.setdefault("VBT_PLAN_FILE", os.path.join(ROOT, "profiles", "plan_lite0"))
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
 # VBT_BENCH_MODEL: rehearsal knob (e.g. a Lite2 container for BASELINE config 4); the contract line is always Lite0
 MODEL = os.environ.get("VBT_BENCH_MODEL", os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm"))
 
@@ -49,7 +49,7 @@ def make_frames(clip_seeds, t0, n_steps, size=320):
     return out
 
 
-def cpu_baseline(n_frames, threads):
+def cpu_leg(n_frames, threads):
     """Oracle (CPU port) on a bounded sample: detector for n_frames frames (OpenMP over frames),
     then OC-SORT + rep analysis in numpy/python over the detections, as 8 clips."""
     from oracle import detector_ref, ocsort_np, velocity
@@ -79,10 +79,25 @@ def cpu_baseline(n_frames, threads):
                                      ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width")])
     t_trk = time.perf_counter() - t1
     n = per * n_clips
-    return {"value": n / (t_det + t_trk), "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": n / (t_det + t_trk), "unit": "frames/s", "cores": threads, "detector_frames_per_s": n / t_det,
+            "tracker_clip_frames_per_s": n / t_trk,
             "sample": f"{n} synthetic 320x320 frames ({n_clips} clips x {per}), oracle/detector.c with {threads} OpenMP threads "
-                      f"({t_det:.2f} s) + oracle OC-SORT/VelocityTracker in numpy, 1 thread ({t_trk:.2f} s)",
-            "host_cpu": _cpu_name(), "host_cores_visible": os.cpu_count()}
+                      f"({t_det:.2f} s) + oracle OC-SORT/VelocityTracker in numpy, 1 thread ({t_trk:.2f} s)"}
+
+
+def cpu_baseline(n_frames):
+    """Two legs: 4 threads - the reference's `--threads` default (track.py:72) - and every core this
+    process may use.  `value` is the all-cores leg.  kind "port": the reference's TFLite CPU path cannot run here."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    allc = max(1, min(avail, 64))
+    leg4 = cpu_leg(max(n_frames // 4, 64), threads=min(4, avail))
+    legn = cpu_leg(n_frames * max(1, allc // 16), threads=allc) if allc > 4 else leg4
+    return {"value": legn["value"], "unit": "frames/s", "cores": legn["cores"], "kind": "port", "sample": legn["sample"],
+            "legs": {"threads_4": leg4, "all_cores": legn}, "host_cpu": _cpu_name(), "host_cores_visible": os.cpu_count(),
+            "host_cores_usable": avail}
 
 
 def _cpu_name():
@@ -119,6 +134,7 @@ def main():
     ap.add_argument("--unique-steps", type=int, default=64, help="distinct frame sets kept in HBM and cycled")
     ap.add_argument("--cpu-frames", type=int, default=2048, help="frames of the CPU baseline sample, about 15-20 s of CPU work (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive pass and the detect-only / track-only splits")
     ap.add_argument("--seed-offset", type=int, default=0, help="rehearsal: run this rank on the clips another rank would own")
     args = ap.parse_args()
 
@@ -157,75 +173,61 @@ def main():
     seeds = [(rank + args.seed_offset) * n + c for c in range(n)]   # ranks own disjoint clips
     from vbt_amd.container import Container
     size = int(Container(MODEL).header["image_size"])
-    frames = torch.from_numpy(make_frames(seeds, 0, U, size)).to(dev)  # resident in HBM before timing
+    frames_np = make_frames(seeds, 0, U, size)
+    frames = torch.from_numpy(frames_np).to(dev)                      # resident in HBM before timing
     pipe = Pipeline(MODEL, n, max_frames=K + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
     stream = torch.cuda.current_stream().cuda_stream
     fbytes = frames[0].numel()
+    PH = 32                                                           # phases kept in the fixed-size result record
+    trace = os.environ.get("VBT_BENCH_TRACE") == "1"
 
-    def run_steps(count, start):
+    def run_steps(count, start, **kw):
         for i in range(count):
-            pipe.step(frames.data_ptr() + ((start + i) % U) * fbytes, stream)
+            pipe.step(frames.data_ptr() + ((start + i) % U) * fbytes, stream, **kw)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     run_steps(W, 0)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     run_steps(K, W)
-    pipe.finish(stream)
-    # result record per clip: [best_id, n_rows, n_phases, 32 x (t0,t1,y0,y1,rom,type)]
-    rec = np.zeros((n, 3 + 32 * 6), np.float64)
-    best, rows_n, nph, ovf, ph = pipe.tracker.summary(cap=512)      # every clip's export id / row count / phases: 4 D2H copies
+    t_enq = time.perf_counter()
+    # clip close inside the timed region: pipeline drain, export-id selection + rep analysis on the device, ONE packed D2H
+    best, rows_n, nph, ovf, ph = pipe.close(cap=PH)
+    t_close = time.perf_counter()
+    # result record per clip: [best_id, n_rows, n_phases, PH x (t0,t1,y0,y1,rom,type)]
+    rec = np.zeros((n, 3 + PH * 6), np.float64)
     nrows = int(rows_n.sum())
     rec[:, 0], rec[:, 1], rec[:, 2] = best, rows_n, nph
-    rec[:, 3:] = ph[:, :32].reshape(n, -1)                          # the fixed-size record keeps the first 32 phases
+    rec[:, 3:] = ph.reshape(n, -1)
     if dist is not None:                                             # the one exchange of the path: RCCL all-gather
-        mine = torch.from_numpy(rec).to(cdev)
-        allrec = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=cdev)   # concatenated layout
-        dist.all_gather_into_tensor(allrec, mine)
-        rec_all = allrec.cpu().numpy().reshape(world, *rec.shape)
+        rec_all = gather_records(dist, rec, world, cdev)
     else:
         rec_all = rec[None]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
+    if trace:
+        print(f"[trace] rank {rank}: enqueue {1e3 * (t_enq - t0):.2f} ms, close {1e3 * (t_close - t_enq):.2f} ms, gather+fence "
+              f"{1e3 * (t0 + dt - t_close):.2f} ms", file=sys.stderr)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     overflow = int((ovf != 0).sum())
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = extra_measurements(torch, pipe, frames, frames_np, n, K, U, fbytes, stream, PH)
     roofline = None
     if rank == 0 and not args.no_roofline:
-        L = _lib.lib()
-        stats = (_lib.KernelStat * 16)()
-        cnt = ctypes.c_int()
-        _lib.check(L.vbt_model_kernel_stats(pipe.interpreter.handle, n, stats, 16, ctypes.byref(cnt)))
-        ms = (ctypes.c_double * 16)()
-        _lib.check(L.vbt_model_profile(pipe.interpreter.handle, frames.data_ptr(), n, 10, stream, ms, 16))
-        fam = max(range(cnt.value), key=lambda i: ms[i])
-        s = stats[fam]
-        per_launch_s = ms[fam] * 1e-3 / s.launches
-        achieved = (s.algorithmic_bytes / s.launches) / per_launch_s
-        traffic = None      # HBM bytes per launch from the separate rocprofv3 --pmc passes of this same plan (profiles/)
-        try:
-            tj = json.load(open(TRAFFIC_JSON))
-            if tj.get("batch") == n and s.name.decode() in tj["families"] and tj["families"][s.name.decode()]["launches"] == s.launches:
-                traffic = tj["families"][s.name.decode()]["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
-        roofline = {"bound": "hbm", "kernel": s.name.decode(), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK, "traffic": traffic, "launches_per_step": s.launches,
-                    "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": s.algorithmic_bytes / s.launches,
-                    "families_ms_per_step": {stats[i].name.decode(): round(ms[i], 4) for i in range(cnt.value)},
-                    "whole_net_algorithmic_GBps": sum(stats[i].algorithmic_bytes for i in range(cnt.value)) /
-                    (sum(ms[i] for i in range(cnt.value)) * 1e-3) / 1e9}
+        roofline = roofline_block(pipe, frames, n, stream)
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
-        cpu = cpu_baseline(args.cpu_frames, threads=max(1, min(16, os.cpu_count() or 1)))
+        cpu = cpu_baseline(args.cpu_frames)
 
     if dist is not None:
         dist.barrier()
@@ -237,16 +239,119 @@ def main():
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "EfficientDet-Lite0 320x320 full-integer (int8 act/weights, int32 acc), synthetic clips "
-                                   "batched frame-wise, decode+NMS+OC-SORT on device every step, export-id selection + "
-                                   "VelocityTracker on device at clip end (inside the timed region)",
+            "config": {"workload": "EfficientDet-Lite0 320x320 full-integer (int8 act/weights, int32 acc; arithmetic of tflite-runtime "
+                                   "2.14's XNNPACK kernels), synthetic clips batched frame-wise, decode+NMS+OC-SORT on device every step, "
+                                   "export-id selection + VelocityTracker on device at clip end (inside the timed region); frames resident in HBM",
                        "clips_per_gpu": n, "batch": n, "frames_per_clip": K, "model_file": os.path.basename(MODEL),
-                       "weights": "seeded synthetic (PCG64), post-training int8 quantised", "parallelism": f"clip-sharded x{world}"},
+                       "weights": "seeded synthetic (PCG64), post-training int8 quantised", "parallelism": f"clip-sharded x{world}",
+                       "pipeline_depth": pipe.depth},
             "rows_emitted_rank0": int(nrows), "tracker_overflow_rank0": int(overflow),
             "clips_with_result": int((rec_all[..., 1] > 0).sum()),
+            "timed_region_ms": {"enqueue": 1e3 * (t_enq - t0), "clip_close": 1e3 * (t_close - t_enq), "total": 1e3 * dt},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        out.update(extras)
         print(json.dumps(out))
+    return 0
+
+
+def gather_records(dist, rec, world, cdev):
+    """The path's one exchange: every rank's fixed-size per-clip result records, one all-gather (RCCL on GPUs)."""
+    import torch
+    mine = torch.from_numpy(rec).to(cdev)
+    allrec = torch.empty((world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=cdev)   # concatenated layout
+    dist.all_gather_into_tensor(allrec, mine)
+    return allrec.cpu().numpy().reshape(world, *rec.shape)
+
+
+def extra_measurements(torch, pipe, frames, frames_np, n, K, U, fbytes, stream, PH):
+    """Rank 0, N = 1, outside the contract's timed region: the SURVEY 8d metric (frames in pinned host memory -> rows on the
+    host, H2D and D2H included) and the detect-only / track-only splits, each over the same K steps."""
+    out = {}
+    Kx = min(K, 200)
+
+    def reset():
+        torch.cuda.synchronize()
+        pipe.reset()
+
+    # ---- H2D-inclusive: uint8 frames in pinned host memory; DataFrame rows of every clip back on the host ----
+    Uh = min(U, 16)
+    host = torch.from_numpy(frames_np[:Uh]).pin_memory()                       # [Uh, n, S, S, 3]
+    rows_host = torch.empty(n * pipe.tracker.rows_cap * 64, dtype=torch.uint8).pin_memory()
+    reset()
+    for i in range(3):
+        pipe.step(host[i % Uh], stream)
+    torch.cuda.synchronize()
+    reset()
+    t0 = time.perf_counter()
+    for i in range(Kx):
+        pipe.step(host[i % Uh], stream)
+    best, rows_n, nph, ovf, ph = pipe.close(cap=PH)
+    counts, rows = pipe.rows_all(out=rows_host)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(counts.sum()) == int(rows_n.sum())
+    out["value_h2d_inclusive"] = Kx * n / dt
+    out["h2d_inclusive"] = {"frames_per_s": Kx * n / dt, "ms_per_step": dt / Kx * 1e3, "steps": Kx,
+                            "h2d_bytes_per_step": int(host[0].numel()), "rows_d2h_bytes": int(counts.max()) * 64 * n,
+                            "note": "uint8 frames in pinned host memory -> hipMemcpyAsync on the slot's stream (overlapped by the depth-3 "
+                                    "pipeline) -> detect+NMS+track -> clip close -> all DataFrame rows copied to pinned host memory"}
+    # ---- splits ----
+    reset()
+    for i in range(3):
+        pipe.step(frames.data_ptr() + (i % U) * fbytes, stream, track=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(Kx):
+        pipe.step(frames.data_ptr() + (i % U) * fbytes, stream, track=False)
+    torch.cuda.synchronize()
+    det_dt = time.perf_counter() - t0
+    reset()
+    pipe.step(frames.data_ptr(), stream)                                       # one real step: detections in slot 0's buffers
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.tracker_only_steps(Kx)
+    torch.cuda.synchronize()
+    trk_dt = time.perf_counter() - t0
+    out["splits"] = {"detect_only": {"frames_per_s": Kx * n / det_dt, "ms_per_step": det_dt / Kx * 1e3,
+                                     "note": f"detector + decode + NMS, {pipe.depth} forwards in flight, no tracker"},
+                     "track_only": {"clip_frames_per_s": Kx * n / trk_dt, "us_per_step": trk_dt / Kx * 1e6,
+                                    "note": "OC-SORT step of all clips on one frame's detections, repeated"}}
+    reset()
+    return out
+
+
+def roofline_block(pipe, frames, n, stream):
+    """Dominant kernel family by HIP-event time on the launch stream (one forward in flight)."""
+    from vbt_amd import _lib
+    L = _lib.lib()
+    stats = (_lib.KernelStat * 16)()
+    cnt = ctypes.c_int()
+    _lib.check(L.vbt_model_kernel_stats(pipe.interpreter.handle, n, stats, 16, ctypes.byref(cnt)))
+    ms = (ctypes.c_double * 16)()
+    _lib.check(L.vbt_model_profile(pipe.interpreter.handle, frames.data_ptr(), n, 10, stream, ms, 16))
+    fam = max(range(cnt.value), key=lambda i: ms[i])
+    s = stats[fam]
+    name = s.name.decode()
+    per_launch_s = ms[fam] * 1e-3 / s.launches
+    achieved = (s.algorithmic_bytes / s.launches) / per_launch_s
+    traffic = counters = None   # from the separate rocprofv3 --pmc passes of this same plan (profiles/, tools/make_profile_summary.py)
+    try:
+        tj = json.load(open(COUNTERS_JSON))
+        fj = tj["families"].get(name)
+        if tj.get("batch") == n and fj and fj["launches"] == s.launches:
+            traffic = fj["hbm_bytes_per_launch"]
+        counters = tj.get("derived")
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"bound": "hbm", "kernel": name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": traffic, "launches_per_step": s.launches,
+            "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": s.algorithmic_bytes / s.launches,
+            "hbm_traffic_GBps": (traffic / per_launch_s / 1e9) if traffic else None,
+            "counters": counters,
+            "families_ms_per_step": {stats[i].name.decode(): round(ms[i], 4) for i in range(cnt.value)},
+            "whole_net_algorithmic_GBps": sum(stats[i].algorithmic_bytes for i in range(cnt.value)) /
+            (sum(ms[i] for i in range(cnt.value)) * 1e-3) / 1e9}
 
 
 if __name__ == "__main__":

@@ -175,6 +175,11 @@ int vbt_tracker_phases(vbt_tracker* t, int clip, int32_t* best_id, double* phase
 /* The same for every clip at once (arrays of n_clips entries; phases6 is [n_clips][cap][6], rows beyond n_phases[c] are
  * not written): export ids, DataFrame row counts, phase counts and overflow flags in four device-to-host copies. */
 int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int32_t* n_phases, int32_t* overflow, double* phases6, int cap);
+/* DataFrame rows (reference track.py:227-234) of EVERY clip in one strided device-to-host copy on `stream` (which the
+ * call synchronises): rows_host = [n_clips][cap] records of 64 bytes {int64 id; double time, x, y, dx, dy,
+ * norm_plate_height, norm_plate_width}, all ids in emission order; counts[c] = number of rows of clip c.
+ * rows_host may be pinned host memory (one DMA) or pageable. */
+int vbt_tracker_rows_all(vbt_tracker* t, int32_t* counts, void* rows_host, int cap, void* stream);
 
 /* ------------------------------------------------------------------ rep analysis ------------
  * Replaces VelocityTracker (reference VelocityTracker.py:15-230) as driven by analyze_df

@@ -159,3 +159,66 @@ def test_frame_major_detection_records_over_gloo(tmp_path):
     scores = np.zeros((2, 25), np.float32); scores[0, :2] = (0.9, 0.4)
     dets, cnt, times = records_to_tracker_inputs(pack_detection_records(boxes, scores, np.array([2, 0])), fps=30.0)
     assert cnt.tolist() == [[1], [0]] and np.allclose(dets[0, 0, 0], (0.2, 0.1, 0.4, 0.3, 0.9, 0.0)) and np.allclose(times[:, 0], (1 / 30, 2 / 30))
+
+
+WORKER_BENCH = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["VBT_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n, PH = 5, 32
+rec = np.zeros((n, 3 + PH * 6), np.float64)
+rec[:, 0] = rank * 100 + np.arange(n)              # best ids
+rec[:, 1] = 10 + rank                               # rows
+rec[:, 3:] = rank + np.arange(PH * 6)[None, :] / 1000.0
+allrec = bench.gather_records(dist, rec, world, torch.device("cpu"))
+ok = allrec.shape == (world, n, 3 + PH * 6) and all(np.array_equal(allrec[r, :, 0], r * 100 + np.arange(n)) and
+                                                    np.all(allrec[r, :, 1] == 10 + r) and allrec[r, 2, 3 + 7] == r + 0.007 for r in range(world))
+if rank == 0:
+    print(json.dumps({"ok": bool(ok), "clips_with_result": int((allrec[..., 1] > 0).sum())}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_bench_gather_layout_two_ranks_over_gloo(tmp_path):
+    """bench.py's result exchange (one all_gather_into_tensor of fixed-size per-clip records, concatenated layout) with two
+    ranks on CPU: rank r's records land in block r, in clip order."""
+    script = tmp_path / "worker_bench.py"
+    script.write_text(WORKER_BENCH)
+    env = dict(os.environ, VBT_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    assert json.loads(outs[0][0].strip().splitlines()[-1]) == {"ok": True, "clips_with_result": 10}
+
+
+def test_bench_self_launches_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (the driver's command shape) must start N fresh rank processes through
+    torch.distributed.run on 127.0.0.1 before touching the GPU, and return their exit code."""
+    import bench
+    calls = {}
+
+    class P:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls["cmd"], calls["env"] = cmd, env
+        return P()
+    import subprocess as sp
+    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    import torch
+    before = torch.cuda.is_initialized()
+    assert bench.main() == 7
+    assert torch.cuda.is_initialized() == before                     # the parent made no GPU call
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -250,3 +250,41 @@ def test_slot_reuse_equals_per_clip_runs(model_path, oracle_lib):
         assert got["id"] == want["id"], c
         for k in ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width"):
             assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), (c, k)
+
+
+def test_host_frames_close_and_rows_all_equal_the_per_clip_accessors(model_path):
+    """The SURVEY 8d path (frames in pinned host memory -> rows on the host): step() on a pinned host tensor, close() (one
+    packed D2H) and rows_all() (one strided D2H) give what device-resident frames + finish() + rows(clip)/phases(clip) give;
+    reset() starts the same clips over."""
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.ocsort import ROW_DTYPE
+    from vbt_amd.track import Pipeline
+    n, T = 3, 9
+    frames = np.stack([np.stack([synth.render(synth.background(300 + c), 4 * c + t) for c in range(n)]) for t in range(T)])
+    st = torch.cuda.current_stream().cuda_stream
+    pipe = Pipeline(model_path, n, max_frames=T, fps=60.0, detection_treshold=0.3, rows_per_frame=25)
+    fd = torch.from_numpy(frames).to("cuda:0")
+    for t in range(T):
+        pipe.step(fd[t], st)
+    pipe.finish(st)
+    want_rows = [pipe.rows(c) for c in range(n)]
+    want_ph = [pipe.phases(c) for c in range(n)]
+    assert sum(len(r["id"]) for r in want_rows) > 10
+    for rep in range(2):                                                  # second round: after reset()
+        pipe.reset()
+        host = torch.from_numpy(frames).pin_memory()
+        for t in range(T):
+            pipe.step(host[t], st)
+        best, rows_n, nph, ovf, ph = pipe.close(cap=8)
+        counts, rows = pipe.rows_all()
+        assert rows.dtype == ROW_DTYPE and rows.shape[0] == n
+        for c in range(n):
+            assert counts[c] == rows_n[c] == len(want_rows[c]["id"]) and ovf[c] == 0
+            for k in ROW_DTYPE.names:
+                assert np.array_equal(rows[c, :counts[c]][k], np.asarray(want_rows[c][k])), (rep, c, k)
+            assert best[c] == want_ph[c][0] and nph[c] == len(want_ph[c][1])
+            assert np.array_equal(ph[c, :nph[c]], want_ph[c][1])
+    pinned = torch.empty(n * pipe.tracker.rows_cap * 64, dtype=torch.uint8).pin_memory()
+    counts2, rows2 = pipe.rows_all(out=pinned)
+    assert np.array_equal(counts2, counts) and all(np.array_equal(rows2[c, :counts[c]], rows[c, :counts[c]]) for c in range(n))

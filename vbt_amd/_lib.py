@@ -54,6 +54,7 @@ _SIGS = {
     "vbt_tracker_phases": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_int32), c_void_p, c_int, ctypes.POINTER(c_int)]),
     "vbt_tracker_update_from_slots": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_float, c_void_p]),
     "vbt_tracker_summary": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "vbt_tracker_rows_all": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vbt_analyze": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_void_p, c_int, ctypes.POINTER(c_int), c_int]),
     "vbt_window_means": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
 }

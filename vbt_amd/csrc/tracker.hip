@@ -640,13 +640,21 @@ __global__ __launch_bounds__(64) void tracker_kernel(ClipState* states, Row* row
 // threshold of reference odt.py:70-75 and the reorder of odt.py:102-118.
 // slot = position in the detector batch; clip = tracker state it feeds (map == nullptr: the same index; a negative entry
 // or a negative time: the slot carries no frame in this step)
+// The per-step metadata (frame time and clip of every slot) travels as a kernel argument: no host-to-device copy, no
+// host buffer that has to outlive the call.  64 slots per launch; larger batches take several launches (slot0).
+constexpr int META_SLOTS = 64;
+struct StepMeta {
+  double time[META_SLOTS];
+  int clip[META_SLOTS];
+};
 __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states, Row* rows, int rows_cap, const float* boxes,
-                                                              const float* scores, const int* counts, const double* times,
-                                                              const int* map, float det_threshold, TrackParams p, double q44, double q66) {
+                                                              const float* scores, const int* counts, StepMeta meta, int slot0,
+                                                              float det_threshold, TrackParams p, double q44, double q66) {
   __shared__ StepShared sh;
-  const int slot = blockIdx.x, lane = threadIdx.x;
-  const int clip = map ? map[slot] : slot;
-  if (clip < 0 || !(times[slot] >= 0.0)) return;
+  const int slot = slot0 + blockIdx.x, lane = threadIdx.x;
+  const int clip = meta.clip[blockIdx.x];
+  const double frame_time = meta.time[blockIdx.x];
+  if (clip < 0 || !(frame_time >= 0.0)) return;
   ClipState& st = states[clip];
   if (lane == 0) {
     int n = counts[slot], m = 0, mk = 0;
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states,
   }
   __syncthreads();
   if (sh.flag < 0) return;
-  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, sh.flag, times[slot], p, q44, q66, lane);
+  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, sh.flag, frame_time, p, q44, q66, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -891,6 +899,23 @@ __global__ __launch_bounds__(64) void select_gather_kernel(ClipState* states, co
   if (lane == 0) T[clip] = outn;
 }
 
+// Clip close: everything the host reads per clip, packed into one block so that ONE copy fetches it:
+//   record c = { int best_id, n_rows, n_phases, overflow ; double phases[cap][6] }
+__global__ __launch_bounds__(64) void pack_summary_kernel(const ClipState* states, const int* best, const int* nph, const double* phases,
+                                                          int cap, unsigned char* out) {
+  const int clip = blockIdx.x, lane = threadIdx.x;
+  const size_t rec = 16 + (size_t)cap * 48;
+  unsigned char* o = out + clip * rec;
+  const int n = nph[clip];
+  if (lane == 0) {
+    int* h = (int*)o;
+    h[0] = best[clip]; h[1] = states[clip].nrows; h[2] = n; h[3] = states[clip].overflow | states[clip].rows_overflow;
+  }
+  double* ph = (double*)(o + 16);
+  const double* src = phases + (size_t)clip * MAXPH * 6;
+  for (int i = lane; i < min(n, cap) * 6; i += 64) ph[i] = src[i];
+}
+
 __global__ void init_states_kernel(ClipState* states, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -915,9 +940,11 @@ struct vbt_tracker {
   int* nph = nullptr;
   int* T = nullptr;
   int* best = nullptr;
-  double* d_times = nullptr;  // [n_clips]
-  int* d_map = nullptr;       // [n_clips] slot -> clip of the current step (vbt_tracker_update_from_slots)
   bool finished = false;
+  hipStream_t finish_stream = nullptr;   // stream vbt_tracker_finish ran on: the close waits for it, not for the device
+  unsigned char* d_summary = nullptr;    // packed close block (pack_summary_kernel), grown on demand
+  unsigned char* h_summary = nullptr;    // its pinned host copy
+  size_t summary_bytes = 0;
 };
 
 extern "C" {
@@ -953,8 +980,6 @@ int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* prm,
   if (hipMalloc((void**)&t->nph, sizeof(int) * n_clips) != hipSuccess) return fail("nph");
   if (hipMalloc((void**)&t->T, sizeof(int) * n_clips) != hipSuccess) return fail("T");
   if (hipMalloc((void**)&t->best, sizeof(int) * n_clips) != hipSuccess) return fail("best");
-  if (hipMalloc((void**)&t->d_times, sizeof(double) * n_clips) != hipSuccess) return fail("times");
-  if (hipMalloc((void**)&t->d_map, sizeof(int) * n_clips) != hipSuccess) return fail("map");
   init_states_kernel<<<(n_clips + 63) / 64, 64>>>(t->states, n_clips);
   VBT_HIP_CHECK(hipDeviceSynchronize());
   *out = t;
@@ -964,7 +989,9 @@ int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* prm,
 void vbt_tracker_destroy(vbt_tracker* t) {
   if (!t) return;
   (void)hipFree(t->states); (void)hipFree(t->rows); (void)hipFree(t->cols); (void)hipFree(t->scratch);
-  (void)hipFree(t->phases); (void)hipFree(t->nph); (void)hipFree(t->T); (void)hipFree(t->best); (void)hipFree(t->d_times); (void)hipFree(t->d_map);
+  (void)hipFree(t->phases); (void)hipFree(t->nph); (void)hipFree(t->T); (void)hipFree(t->best);
+  if (t->d_summary) (void)hipFree(t->d_summary);
+  if (t->h_summary) (void)hipHostFree(t->h_summary);
   delete t;
 }
 
@@ -995,16 +1022,28 @@ int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts
   return VBT_OK;
 }
 
-int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
-                                       const double* times_host, float det_threshold, void* stream) {
-  if (!t || !boxes_dev || !scores_dev || !counts_dev || !times_host) { set_error("bad argument"); return VBT_ERR_ARG; }
-  hipStream_t st = (hipStream_t)stream;
-  VBT_HIP_CHECK(hipMemcpyAsync(t->d_times, times_host, sizeof(double) * t->n_clips, hipMemcpyHostToDevice, st));
-  tracker_from_det_kernel<<<t->n_clips, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, t->d_times,
-                                                     nullptr, det_threshold, t->p, t->q44, t->q66);
+// One tracker step for slots [0, n_slots): launches of at most META_SLOTS workgroups, metadata in the kernel arguments.
+static int launch_steps(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev, const int32_t* clip_of_slot,
+                        const double* times, int n_slots, float det_threshold, hipStream_t st) {
+  for (int s0 = 0; s0 < n_slots; s0 += META_SLOTS) {
+    const int nb = std::min(META_SLOTS, n_slots - s0);
+    StepMeta meta;
+    for (int i = 0; i < nb; i++) {
+      meta.time[i] = times[s0 + i];
+      meta.clip[i] = clip_of_slot ? clip_of_slot[s0 + i] : s0 + i;
+    }
+    tracker_from_det_kernel<<<nb, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, meta, s0, det_threshold,
+                                               t->p, t->q44, t->q66);
+  }
   VBT_HIP_CHECK(hipGetLastError());
   t->finished = false;
   return VBT_OK;
+}
+
+int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
+                                       const double* times_host, float det_threshold, void* stream) {
+  if (!t || !boxes_dev || !scores_dev || !counts_dev || !times_host) { set_error("bad argument"); return VBT_ERR_ARG; }
+  return launch_steps(t, boxes_dev, scores_dev, counts_dev, nullptr, times_host, t->n_clips, det_threshold, (hipStream_t)stream);
 }
 
 int vbt_tracker_update_from_slots(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
@@ -1019,14 +1058,7 @@ int vbt_tracker_update_from_slots(vbt_tracker* t, const float* boxes_dev, const 
     for (int j = 0; j < i; j++)
       if (clip_of_slot_host[i] >= 0 && clip_of_slot_host[i] == clip_of_slot_host[j]) { set_error("clip %d sits in two slots", clip_of_slot_host[i]); return VBT_ERR_ARG; }
   }
-  hipStream_t st = (hipStream_t)stream;
-  VBT_HIP_CHECK(hipMemcpyAsync(t->d_times, times_host, sizeof(double) * n_slots, hipMemcpyHostToDevice, st));
-  VBT_HIP_CHECK(hipMemcpyAsync(t->d_map, clip_of_slot_host, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
-  tracker_from_det_kernel<<<n_slots, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, t->d_times, t->d_map,
-                                                  det_threshold, t->p, t->q44, t->q66);
-  VBT_HIP_CHECK(hipGetLastError());
-  t->finished = false;
-  return VBT_OK;
+  return launch_steps(t, boxes_dev, scores_dev, counts_dev, clip_of_slot_host, times_host, n_slots, det_threshold, (hipStream_t)stream);
 }
 
 static int fetch_state_header(vbt_tracker* t, int clip, ClipState* hdr_only) {
@@ -1113,6 +1145,7 @@ int vbt_tracker_finish(vbt_tracker* t, double plate_diameter, double diff_thresh
   analyze_kernel<<<t->n_clips, 64, 0, st>>>(t->cols, t->T, t->rows_cap, vp, t->scratch, t->phases, t->nph);
   VBT_HIP_CHECK(hipGetLastError());
   t->finished = true;
+  t->finish_stream = st;
   return VBT_OK;
 }
 
@@ -1189,30 +1222,62 @@ int vbt_window_means(const double* rows, int T, int ncols, const int32_t* window
   return VBT_OK;
 }
 
+// Clip close, host side: one pack kernel, ONE asynchronous copy into pinned memory, ONE stream synchronisation (on the
+// stream vbt_tracker_finish ran on - not a device-wide one).
 int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int32_t* n_phases, int32_t* overflow, double* phases6, int cap) {
   if (!t || !best_ids || !n_rows || !n_phases || !overflow || !phases6 || cap < 1) { set_error("bad argument"); return VBT_ERR_ARG; }
   if (!t->finished) { set_error("vbt_tracker_summary before vbt_tracker_finish"); return VBT_ERR_STATE; }
-  VBT_HIP_CHECK(hipDeviceSynchronize());
   const int n = t->n_clips;
-  std::vector<int> nph(n);
-  VBT_HIP_CHECK(hipMemcpy(nph.data(), t->nph, sizeof(int) * n, hipMemcpyDeviceToHost));
-  VBT_HIP_CHECK(hipMemcpy(best_ids, t->best, sizeof(int) * n, hipMemcpyDeviceToHost));
-  // per-clip state headers: one strided 2D copy instead of n small ones
+  cap = std::min(cap, MAXPH);
+  const size_t rec = 16 + (size_t)cap * 48, bytes = rec * n;
+  if (bytes > t->summary_bytes) {
+    if (t->d_summary) (void)hipFree(t->d_summary);
+    if (t->h_summary) (void)hipHostFree(t->h_summary);
+    t->d_summary = nullptr; t->h_summary = nullptr; t->summary_bytes = 0;
+    VBT_HIP_CHECK(hipMalloc((void**)&t->d_summary, bytes));
+    VBT_HIP_CHECK(hipHostMalloc((void**)&t->h_summary, bytes, hipHostMallocDefault));
+    t->summary_bytes = bytes;
+  }
+  hipStream_t st = t->finish_stream;
+  pack_summary_kernel<<<n, 64, 0, st>>>(t->states, t->best, t->nph, t->phases, cap, t->d_summary);
+  VBT_HIP_CHECK(hipMemcpyAsync(t->h_summary, t->d_summary, bytes, hipMemcpyDeviceToHost, st));
+  VBT_HIP_CHECK(hipStreamSynchronize(st));
+  for (int c = 0; c < n; c++) {
+    const unsigned char* r = t->h_summary + c * rec;
+    const int* h = (const int*)r;
+    best_ids[c] = h[0]; n_rows[c] = h[1]; n_phases[c] = h[2]; overflow[c] = h[3];
+    if (h[2] > cap) { set_error("clip %d has %d phases, buffer holds %d", c, h[2], cap); return VBT_ERR_CAPACITY; }
+    memcpy(phases6 + (size_t)c * cap * 6, r + 16, (size_t)h[2] * 48);
+  }
+  return VBT_OK;
+}
+
+// DataFrame rows of EVERY clip (all ids, emission order) in one strided copy: rows_host = [n_clips][cap] records of
+// 64 bytes {int64 id; double time, x, y, dx, dy, norm_plate_height, norm_plate_width} (reference track.py:227-234).
+// counts[c] = rows of clip c.  rows_host may be pinned (then the copy is one DMA) or pageable.
+int vbt_tracker_rows_all(vbt_tracker* t, int32_t* counts, void* rows_host, int cap, void* stream) {
+  if (!t || !counts || !rows_host || cap < 1) { set_error("vbt_tracker_rows_all: bad argument"); return VBT_ERR_ARG; }
+  static_assert(sizeof(Row) == 64, "row record");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = t->n_clips;
   const size_t hdr = offsetof(ClipState, last_out);
   std::vector<char> heads((size_t)n * hdr);
-  VBT_HIP_CHECK(hipMemcpy2D(heads.data(), hdr, t->states, sizeof(ClipState), hdr, n, hipMemcpyDeviceToHost));
+  VBT_HIP_CHECK(hipMemcpy2DAsync(heads.data(), hdr, t->states, sizeof(ClipState), hdr, n, hipMemcpyDeviceToHost, st));
+  VBT_HIP_CHECK(hipStreamSynchronize(st));
   int most = 0;
   for (int c = 0; c < n; c++) {
-    const ClipState* st = (const ClipState*)(heads.data() + (size_t)c * hdr);
-    n_rows[c] = st->nrows;
-    overflow[c] = st->overflow | st->rows_overflow;
-    n_phases[c] = nph[c];
-    if (nph[c] > cap) { set_error("clip %d has %d phases, buffer holds %d", c, nph[c], cap); return VBT_ERR_CAPACITY; }
-    most = std::max(most, nph[c]);
+    const ClipState* cs = (const ClipState*)(heads.data() + (size_t)c * hdr);
+    if (cs->overflow > 0) { set_error("clip %d: more than %d live tracks (%d births dropped)", c, MAXT, cs->overflow); return VBT_ERR_CAPACITY; }
+    if (cs->rows_overflow > 0) { set_error("clip %d: row capacity %d exceeded by %d", c, t->rows_cap, cs->rows_overflow); return VBT_ERR_CAPACITY; }
+    if (cs->nrows > cap) { set_error("clip %d has %d rows, buffer holds %d", c, cs->nrows, cap); return VBT_ERR_CAPACITY; }
+    counts[c] = cs->nrows;
+    most = std::max(most, cs->nrows);
   }
-  if (most > 0)
-    VBT_HIP_CHECK(hipMemcpy2D(phases6, sizeof(double) * 6 * cap, t->phases, sizeof(double) * 6 * MAXPH, sizeof(double) * 6 * most, n,
-                              hipMemcpyDeviceToHost));
+  if (most > 0) {
+    VBT_HIP_CHECK(hipMemcpy2DAsync(rows_host, sizeof(Row) * (size_t)cap, t->rows, sizeof(Row) * (size_t)t->rows_cap, sizeof(Row) * (size_t)most, n,
+                                   hipMemcpyDeviceToHost, st));
+    VBT_HIP_CHECK(hipStreamSynchronize(st));
+  }
   return VBT_OK;
 }
 

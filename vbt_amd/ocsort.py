@@ -108,6 +108,31 @@ def _summary(self, cap=64):
 
 MultiClipTracker.summary = _summary
 
+ROW_DTYPE = np.dtype([("id", "<i8"), ("time", "<f8"), ("x", "<f8"), ("y", "<f8"), ("dx", "<f8"), ("dy", "<f8"),
+                      ("norm_plate_height", "<f8"), ("norm_plate_width", "<f8")])       # the 8 columns of reference track.py:227-234
+
+
+def _rows_all(self, cap=None, out=None, stream=None):
+    """Rows of every clip in one strided copy: (counts[n], rows[n, cap] of ROW_DTYPE).  `out`: optional preallocated
+    (pinned) buffer of at least n * cap * 64 bytes exposing .data_ptr() (torch) or the numpy buffer protocol."""
+    n = self.n_clips
+    cap = int(cap or self.rows_cap)
+    counts = np.zeros(n, np.int32)
+    if out is None:
+        rows = np.zeros((n, cap), ROW_DTYPE)
+        ptr = rows.ctypes.data
+    elif hasattr(out, "data_ptr"):
+        rows = out.numpy().view(np.uint8).reshape(-1)[:n * cap * 64].view(ROW_DTYPE).reshape(n, cap)
+        ptr = out.data_ptr()
+    else:
+        rows = np.frombuffer(out, np.uint8)[:n * cap * 64].view(ROW_DTYPE).reshape(n, cap)
+        ptr = rows.ctypes.data
+    _lib.check(_lib.lib().vbt_tracker_rows_all(self._h, counts.ctypes.data, ptr, cap, stream))
+    return counts, rows
+
+
+MultiClipTracker.rows_all = _rows_all
+
 
 class OCSort:
     """Single-clip tracker with the reference's call shape (reference track.py:157,186-199)."""

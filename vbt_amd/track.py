@@ -119,7 +119,6 @@ class Pipeline:
                       for _ in range(self.depth)]
         self._times = [np.zeros(n, np.float64) for _ in range(self.depth)]
         self._maps = [None] * self.depth             # per-slot clip maps of the steps in flight
-        self._host_ring = []                         # host arrays handed to asynchronous copies (see _enqueue_tracker)
         self._det_streams = [torch.cuda.Stream(device=tdev) for _ in range(self.depth)]
         self._trk_stream = torch.cuda.Stream(device=tdev)
         self._ev_in = [torch.cuda.Event() for _ in range(self.depth)]
@@ -127,18 +126,15 @@ class Pipeline:
         self._ev_trk = [None] * self.depth          # tracker finished reading slot k's outputs
         self._pending = []                          # slots whose tracker step has not been enqueued yet
         self._resized = [None] * self.depth         # per-slot network-resolution frames (source-resolution input)
+        self._staged = [None] * self.depth          # per-slot device copies of host frames (step() on pinned host memory)
 
     def _enqueue_tracker(self, k):
         T = self._trk_stream
         T.wait_event(self._ev_det[k])
         b, s, c, cnt = self._bufs[k]
-        # the library copies these small host arrays with hipMemcpyAsync; private copies that nothing overwrites (kept for the
-        # next 32 tracker steps) make that safe whether the runtime stages pageable memory at call time or not
-        tm = self._times[k].copy()
-        mp = self._maps[k].copy() if self._maps[k] is not None else None
-        self._host_ring.append((tm, mp))
-        if len(self._host_ring) > 32:
-            self._host_ring.pop(0)
+        # frame times / clip map of the step travel in the kernel arguments (read during the call, no copy in flight)
+        tm = self._times[k]
+        mp = self._maps[k]
         if mp is not None:
             _lib.check(_lib.lib().vbt_tracker_update_from_slots(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
                                                                 mp.ctypes.data, tm.ctypes.data, self.n, self.thr, T.cuda_stream))
@@ -149,7 +145,7 @@ class Pipeline:
         ev.record(T)
         self._ev_trk[k] = ev
 
-    def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False, active=None, clip_map=None, frame_idx=None):
+    def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False, active=None, clip_map=None, frame_idx=None, track=True):
         """frames_dev_ptr: uint8 [n,H,W,3] on the device (frame `frame_count+1` of every clip), valid on the caller's current
         torch stream: either a torch tensor (preferred: its lifetime is then handled here) or a raw device pointer, which
         the caller must keep alive and unmodified until the step has run (up to `depth` steps later).  src_hw=(H, W) of the source frames when they are not at the network
@@ -168,15 +164,28 @@ class Pipeline:
         self._step_idx += 1
         self.frame_count += 1
         S = self._det_streams[k]
+        host_frames = None
         if hasattr(frames_dev_ptr, "data_ptr"):
-            # a torch tensor: its storage is used on the slot's stream, up to `depth` steps after this call returns; tell the
-            # caching allocator, so that dropping the tensor does not hand the memory to a later batch too early
-            frames_dev_ptr.record_stream(S)
-            frames_dev_ptr = frames_dev_ptr.data_ptr()
+            if frames_dev_ptr.device.type == "cpu":
+                # frames in (pinned) host memory, the reference's situation (track.py:160 hands every frame over from the
+                # host): the H2D copy is enqueued on the slot's stream, so it overlaps the forwards of the other slots.  The
+                # caller must leave the host buffer untouched until the step has run (up to `depth` steps later).
+                host_frames = frames_dev_ptr
+            else:
+                # a device tensor: its storage is used on the slot's stream, up to `depth` steps after this call returns; tell
+                # the caching allocator, so that dropping the tensor does not hand the memory to a later batch too early
+                frames_dev_ptr.record_stream(S)
+                frames_dev_ptr = frames_dev_ptr.data_ptr()
         self._ev_in[k].record(torch.cuda.current_stream())           # frames are ready once the caller's stream gets here
         S.wait_event(self._ev_in[k])
         if self._ev_trk[k] is not None:
             S.wait_event(self._ev_trk[k])                            # the tracker is done with this slot's previous outputs
+        if host_frames is not None:
+            if self._staged[k] is None or self._staged[k].shape != host_frames.shape:
+                self._staged[k] = torch.empty(host_frames.shape, dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
+            with torch.cuda.stream(S):
+                self._staged[k].copy_(host_frames, non_blocking=True)
+            frames_dev_ptr = self._staged[k].data_ptr()
         size = int(self.interpreter.get_input_details()[0]["shape"][1])
         if src_hw is not None and (tuple(src_hw) != (size, size) or swap_rb):
             if self._resized[k] is None:
@@ -202,9 +211,37 @@ class Pipeline:
         _lib.check(_lib.lib().vbt_detect_async(self.interpreters[k].handle, frames_dev_ptr, self.n, S.cuda_stream, b.data_ptr(),
                                                s.data_ptr(), c.data_ptr(), cnt.data_ptr()))
         self._ev_det[k].record(S)
+        if not track:                                                # detector-only step (measurement splits)
+            return
         self._pending.append(k)
         while len(self._pending) >= self.depth:                      # keep depth-1 detector steps ahead of the tracker
             self._enqueue_tracker(self._pending.pop(0))
+
+    def reset(self):
+        """Back to frame 0 of fresh clips (tracker state cleared); models, streams and buffers are kept."""
+        self._drain()
+        self._torch.cuda.synchronize()
+        self.tracker.reset()
+        self.frame_count = 0
+        self._step_idx = 0
+        self._ev_trk = [None] * self.depth
+        if hasattr(self, "_clip_frames"):
+            self._clip_frames[:] = 0
+
+    def tracker_only_steps(self, count, slot=0):
+        """Measurement split: `count` tracker steps of all clips on the detections sitting in ring slot `slot`."""
+        b, s, c, cnt = self._bufs[slot]
+        T = self._trk_stream
+        T.wait_event(self._ev_det[slot])
+        tm = np.empty(self.n, np.float64)
+        for i in range(count):
+            self.frame_count += 1
+            np.divide(float(self.frame_count), self.fps[:self.n], out=tm)
+            _lib.check(_lib.lib().vbt_tracker_update_from_detections(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
+                                                                     tm.ctypes.data, self.thr, T.cuda_stream))
+        ev = self._torch.cuda.Event()
+        ev.record(T)
+        self._ev_trk[slot] = ev
 
     def skip_frames(self, n=1):
         """Frames read from the source but not processed (`frame_count % 16` of reference track.py:161-167): they advance
@@ -219,6 +256,19 @@ class Pipeline:
         self._drain()
         self.tracker.finish(self.plate_diameter, stream=self._trk_stream.cuda_stream)
         self._trk_stream.synchronize()
+
+    def close(self, cap=32):
+        """Clip close in one go: drain the pipeline, export-id selection + rep analysis on the device, then ONE packed
+        device-to-host copy and ONE stream synchronisation.  Returns (best_ids[n], n_rows[n], n_phases[n], overflow[n],
+        phases[n, cap, 6]) - per clip the id of reference track.py:107-115 and the Phase list of plot.py:33-47."""
+        self._drain()
+        self.tracker.finish(self.plate_diameter, stream=self._trk_stream.cuda_stream)
+        return self.tracker.summary(cap=cap)
+
+    def rows_all(self, cap=None, out=None):
+        """DataFrame rows of every clip, one strided copy (after close() / finish())."""
+        self._drain()
+        return self.tracker.rows_all(cap=cap, out=out, stream=self._trk_stream.cuda_stream)
 
     def rows(self, clip):
         self._drain()
