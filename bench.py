@@ -88,16 +88,34 @@ def cpu_leg(n_frames, threads):
 def cpu_baseline(n_frames):
     """Two legs: 4 threads - the reference's `--threads` default (track.py:72) - and every core this
     process may use.  `value` is the all-cores leg.  kind "port": the reference's TFLite CPU path cannot run here."""
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    allc = max(1, min(avail, 64))
+    avail = usable_cores()
+    allc = max(1, min(avail, 32))         # beyond ~32 threads the frame-parallel port stops scaling (memory-bound scalar loops)
     leg4 = cpu_leg(max(n_frames // 4, 64), threads=min(4, avail))
-    legn = cpu_leg(n_frames * max(1, allc // 16), threads=allc) if allc > 4 else leg4
+    legn = cpu_leg(n_frames, threads=allc) if allc > 4 else leg4
     return {"value": legn["value"], "unit": "frames/s", "cores": legn["cores"], "kind": "port", "sample": legn["sample"],
             "legs": {"threads_4": leg4, "all_cores": legn}, "host_cpu": _cpu_name(), "host_cores_visible": os.cpu_count(),
             "host_cores_usable": avail}
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def _cpu_name():
@@ -132,7 +150,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU = detector batch")
     ap.add_argument("--unique-steps", type=int, default=64, help="distinct frame sets kept in HBM and cycled")
-    ap.add_argument("--cpu-frames", type=int, default=2048, help="frames of the CPU baseline sample, about 15-20 s of CPU work (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=2048, help="frames of the all-cores CPU baseline leg (the 4-thread leg takes a quarter); about 25 s of CPU work in all (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive pass and the detect-only / track-only splits")
     ap.add_argument("--seed-offset", type=int, default=0, help="rehearsal: run this rank on the clips another rank would own")

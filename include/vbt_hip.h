@@ -107,6 +107,14 @@ typedef struct {
   double macs;
 } vbt_kernel_stat;
 int vbt_model_kernel_stats(const vbt_model* m, int B, vbt_kernel_stat* out, int cap, int* n);
+/* Per-launch profile of the execution plan (one forward in flight, HIP events around every launch; average of `reps`):
+ * entry i = launch i of the forward.  `op` / `first_op` = last / first graph op the launch covers. */
+typedef struct {
+  char family[32];
+  int op, first_op, variant;
+  double ms, algorithmic_bytes, macs;
+} vbt_step_time;
+int vbt_model_profile_steps(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream, vbt_step_time* out, int cap, int* n);
 
 /* Time each kernel family with HIP events on `stream` over `reps` forwards of batch B
  * (frames must be device-resident). ms_out[i] = average milliseconds per forward spent in

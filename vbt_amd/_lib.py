@@ -23,6 +23,11 @@ class KernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 32), ("launches", c_int), ("algorithmic_bytes", c_double), ("macs", c_double)]
 
 
+class StepTime(ctypes.Structure):
+    _fields_ = [("family", ctypes.c_char * 32), ("op", c_int), ("first_op", c_int), ("variant", c_int), ("ms", c_double),
+                ("algorithmic_bytes", c_double), ("macs", c_double)]
+
+
 _SIGS = {
     "vbt_last_error": (c_char_p, []),
     "vbt_device_count": (c_int, []),
@@ -41,6 +46,7 @@ _SIGS = {
     "vbt_resize_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vbt_model_kernel_stats": (c_int, [c_void_p, c_int, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),
     "vbt_model_profile": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_double), c_int]),
+    "vbt_model_profile_steps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(StepTime), c_int, ctypes.POINTER(c_int)]),
     "vbt_tracker_create": (c_int, [c_int, c_int, ctypes.POINTER(TrackerParams), c_int, ctypes.POINTER(c_void_p)]),
     "vbt_tracker_destroy": (None, [c_void_p]),
     "vbt_tracker_reset": (c_int, [c_void_p]),

@@ -2703,4 +2703,40 @@ int vbt_model_profile(vbt_model* m, const uint8_t* frames_dev, int B, int reps, 
   return rc;
 }
 
+// Per-launch timing of the plan (one forward in flight, HIP events around every launch): step i of the execution list ->
+// family name, index of the last graph op it covers, kernel variant and milliseconds (average over `reps`).
+int vbt_model_profile_steps(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream, vbt_step_time* out, int cap, int* n) {
+  if (!m || !frames_dev || !out || !n || reps < 1) { set_error("bad argument"); return VBT_ERR_ARG; }
+  if (B < 1 || B > m->max_batch) { set_error("bad batch"); return VBT_ERR_CAPACITY; }
+  const int ns = (int)m->steps.size();
+  if (cap < ns) { set_error("%d plan steps, buffer holds %d", ns, cap); return VBT_ERR_CAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<hipEvent_t> evs(ns + 1);
+  for (auto& e : evs) VBT_HIP_CHECK(hipEventCreate(&e));
+  for (int i = 0; i < ns; i++) {
+    const Step& s = m->steps[i];
+    memset(&out[i], 0, sizeof(out[i]));
+    snprintf(out[i].family, sizeof(out[i].family), "%s", kFamilyName[s.family]);
+    out[i].op = s.op;
+    out[i].first_op = s.e_op >= 0 ? s.e_op : (s.sum_op >= 0 ? s.sum_op : (s.d_op >= 0 ? s.d_op : s.op));
+    out[i].variant = s.variant;
+    out[i].algorithmic_bytes = s.alg_bytes_per_frame * B + s.weight_bytes;
+    out[i].macs = s.macs_per_frame * B;
+  }
+  int rc = VBT_OK;
+  for (int r = 0; r < reps && rc == VBT_OK; r++) {
+    rc = enqueue_forward(m, frames_dev, B, st, m->out_boxes, m->out_scores, m->out_classes, m->out_counts, evs.data());
+    if (rc) break;
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("stream sync failed"); rc = VBT_ERR_HIP; break; }
+    for (int i = 0; i < ns; i++) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, evs[i], evs[i + 1]);
+      out[i].ms += ms / reps;
+    }
+  }
+  for (auto& e : evs) (void)hipEventDestroy(e);
+  *n = ns;
+  return rc;
+}
+
 }  // extern "C"

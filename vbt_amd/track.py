@@ -126,7 +126,12 @@ class Pipeline:
         self._ev_trk = [None] * self.depth          # tracker finished reading slot k's outputs
         self._pending = []                          # slots whose tracker step has not been enqueued yet
         self._resized = [None] * self.depth         # per-slot network-resolution frames (source-resolution input)
-        self._staged = [None] * self.depth          # per-slot device copies of host frames (step() on pinned host memory)
+        # step() on pinned host memory: H2D copies run on their own stream into a ring of depth + 2 staging buffers, i.e. up
+        # to two steps ahead of the forwards, so that a slot's forward never waits for its own copy
+        self._stage = [None] * (self.depth + 2)
+        self._stage_free = [None] * (self.depth + 2)
+        self._stage_idx = 0
+        self._copy_stream = torch.cuda.Stream(device=tdev)
 
     def _enqueue_tracker(self, k):
         T = self._trk_stream
@@ -180,12 +185,22 @@ class Pipeline:
         S.wait_event(self._ev_in[k])
         if self._ev_trk[k] is not None:
             S.wait_event(self._ev_trk[k])                            # the tracker is done with this slot's previous outputs
+        stage_j = None
         if host_frames is not None:
-            if self._staged[k] is None or self._staged[k].shape != host_frames.shape:
-                self._staged[k] = torch.empty(host_frames.shape, dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
-            with torch.cuda.stream(S):
-                self._staged[k].copy_(host_frames, non_blocking=True)
-            frames_dev_ptr = self._staged[k].data_ptr()
+            stage_j = j = self._stage_idx % len(self._stage)
+            self._stage_idx += 1
+            if self._stage[j] is None or self._stage[j].shape != host_frames.shape:
+                self._stage[j] = torch.empty(host_frames.shape, dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
+            C = self._copy_stream
+            C.wait_event(self._ev_in[k])
+            if self._stage_free[j] is not None:
+                C.wait_event(self._stage_free[j])                    # the forward that last read this staging buffer is done
+            with torch.cuda.stream(C):
+                self._stage[j].copy_(host_frames, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(C)
+            S.wait_event(ev)
+            frames_dev_ptr = self._stage[j].data_ptr()
         size = int(self.interpreter.get_input_details()[0]["shape"][1])
         if src_hw is not None and (tuple(src_hw) != (size, size) or swap_rb):
             if self._resized[k] is None:
@@ -211,6 +226,10 @@ class Pipeline:
         _lib.check(_lib.lib().vbt_detect_async(self.interpreters[k].handle, frames_dev_ptr, self.n, S.cuda_stream, b.data_ptr(),
                                                s.data_ptr(), c.data_ptr(), cnt.data_ptr()))
         self._ev_det[k].record(S)
+        if stage_j is not None:
+            ev = torch.cuda.Event()
+            ev.record(S)
+            self._stage_free[stage_j] = ev
         if not track:                                                # detector-only step (measurement splits)
             return
         self._pending.append(k)
