@@ -337,11 +337,13 @@ static float iou(box_t a, box_t b) {
   return inter / (area_a + area_b - inter);
 }
 
-typedef struct { int32_t q; int32_t idx; } cand_t;
+/* DecreasingArgSort of detection_postprocess.cc: std::stable_sort on the float SCORES, descending.  Two class bytes on a
+ * plateau of the LOGISTIC table have the same score and therefore keep their anchor order. */
+typedef struct { float score; int32_t q; int32_t idx; } cand_t;
 static int cand_cmp(const void* pa, const void* pb) {
   const cand_t* a = (const cand_t*)pa; const cand_t* b = (const cand_t*)pb;
-  if (a->q != b->q) return b->q - a->q;  /* score descending */
-  return a->idx - b->idx;                /* ties: lower anchor index first */
+  if (a->score != b->score) return a->score > b->score ? -1 : 1;  /* score descending */
+  return a->idx - b->idx;                                         /* equal scores: lower anchor index first (stable) */
 }
 
 static int run_postprocess(vbto_model* m, const op_t* op, float* boxes, float* scores, float* classes, int32_t* count) {
@@ -387,7 +389,7 @@ static int run_postprocess(vbto_model* m, const op_t* op, float* boxes, float* s
   int nc = 0;
   for (int i = 0; i < A; i++) { /* SelectDetectionsAboveScoreThreshold: score >= threshold */
     float s = score_lut[cls[i] + 128];
-    if (s >= m->hdr.nms_score_threshold) { cand[nc].q = cls[i]; cand[nc].idx = i; nc++; }
+    if (s >= m->hdr.nms_score_threshold) { cand[nc].score = s; cand[nc].q = cls[i]; cand[nc].idx = i; nc++; }
   }
   qsort(cand, nc, sizeof(cand_t), cand_cmp); /* DecreasingArgSort is a stable sort: ties keep anchor order */
   box_t sel[64];

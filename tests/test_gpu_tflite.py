@@ -61,3 +61,34 @@ def test_cli_accepts_tflite(imported, tmp_path):
     assert "rows" in res.output
     files = os.listdir(out)
     assert len(files) <= 1 and all(f.endswith("_lite0.pkl.gz") for f in files)
+
+
+def test_foreign_encoded_tiny_model_hip_equals_oracle(tmp_path, oracle_lib):
+    """A .tflite written by the independent encoder of tests/tflite_minienc.py (32x32 image, 8-channel graph, shared head
+    weights, non-unit box scales, score plateaus in the LOGISTIC table): imported, then HIP == oracle for every tensor and
+    every detection in three plan modes."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tflite_minienc import TinyModel
+    from vbt_amd.interpreter import Interpreter
+    m = TinyModel(S=32, seed=5).build()
+    path = str(tmp_path / "tiny.tflite")
+    open(path, "wb").write(m.serialize())
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (5, 32, 32, 3), dtype=np.uint8)
+    frames[1] = 0
+    frames[2] = 255
+    for flags in (1, 8, 0):
+        it = Interpreter(model_path=path, max_batch=5, flags=flags)
+        assert tuple(it.get_input_details()[0]["shape"]) == (1, 32, 32, 3)
+        boxes, scores, classes, counts = it.detect(frames)
+        from vbt_amd.tflite_import import convert
+        vb = str(tmp_path / f"tiny{flags}.vbtm")
+        convert(path, vb)
+        det = oracle_lib.OracleDetector(vb)
+        for b in range(5):
+            ob, os_, oc, on = det.run(frames[b])
+            assert counts[b] == on and np.array_equal(scores[b], os_) and np.array_equal(boxes[b], ob), (flags, b)
+            for tid in range(1, it.num_tensors() - 1):
+                if it.materialized(tid):
+                    assert np.array_equal(it.read_tensor(tid, 5)[b], det.tensor(tid)), (flags, tid, b)

@@ -616,8 +616,12 @@ struct PostArgs {
   const int8_t* box[5];
   int base[6];         // first anchor index of each level, base[5] = A
   const float* anchors;  // [A][4] ycenter, xcenter, h, w
-  const unsigned char* tables;  // score f32[256] | box f32[256] | dq f64[256] | ex f64[256] | scales f32[4] (vbt_amd/quant.py)
-  int A, max_det, qmin;  // qmin: lowest int8 class value whose score >= nms_score_threshold (128 = none)
+  // device tables built at model load from the container's (vbt_amd/quant.py): score f32[256] indexed by RANK byte + 128 |
+  // dq f64[256] | ex f64[256] indexed by box byte + 128 | rank int8[256] indexed by class byte + 128.
+  // rank byte: class bytes with EQUAL scores (plateaus of the LOGISTIC table) share one, higher score = higher rank byte,
+  // so that sorting by (rank desc, anchor asc) is the reference's stable sort on the float scores.
+  const unsigned char* tables;
+  int A, max_det, qmin;  // qmin: lowest RANK byte whose score >= nms_score_threshold (128 = none)
   float iou_thr;
 };
 constexpr int POST_CAP = 2048;
@@ -651,9 +655,11 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
     box[l] = p.box[l] + b * (long)nl * 4;
   }
   hist[tid] = 0;
+  __shared__ signed char s_rank[256];
   s_score[tid] = ((const float*)p.tables)[tid];
-  s_dq[tid] = ((const double*)(p.tables + 2048))[tid];
-  s_ex[tid] = ((const double*)(p.tables + 4096))[tid];
+  s_dq[tid] = ((const double*)(p.tables + 1024))[tid];
+  s_ex[tid] = ((const double*)(p.tables + 3072))[tid];
+  s_rank[tid] = ((const signed char*)(p.tables + 5120))[tid];
   if (tid == 0) { s_nsel = 0; s_done = 0; }
   __syncthreads();
   // pass 1: histogram of the class bytes
@@ -664,10 +670,10 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
       for (int i = tid; i < (nl >> 2); i += 256) {
         const unsigned u = c4[i];
 #pragma unroll
-        for (int e = 0; e < 4; e++) atomicAdd(&hist[(int)(int8_t)(u >> (8 * e)) + 128], 1);
+        for (int e = 0; e < 4; e++) atomicAdd(&hist[(int)s_rank[((u >> (8 * e)) & 255u) ^ 128u] + 128], 1);
       }
     } else {
-      for (int i = tid; i < nl; i += 256) atomicAdd(&hist[(int)cls[l][i] + 128], 1);
+      for (int i = tid; i < nl; i += 256) atomicAdd(&hist[(int)s_rank[(int)cls[l][i] + 128] + 128], 1);
     }
   }
   __syncthreads();
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
           const unsigned u = c4[i4];
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            const int q = (int)(int8_t)(u >> (8 * e));
+            const int q = (int)s_rank[((u >> (8 * e)) & 255u) ^ 128u];
             if (q >= qlo && q <= qhi) {
               int pos = atomicAdd(&s_n, 1);
               keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)(lo + 4 * i4 + e);
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
           }
         }
         for (int i = lo + 4 * n4 + tid; i < hi; i += 256) {
-          int q = cls[l][i - p.base[l]];
+          int q = s_rank[(int)cls[l][i - p.base[l]] + 128];
           if (q >= qlo && q <= qhi) {
             int pos = atomicAdd(&s_n, 1);
             keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)i;
@@ -719,7 +725,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
         }
       } else {
         for (int i = lo + tid; i < hi; i += 256) {
-          int q = cls[l][i - p.base[l]];
+          int q = s_rank[(int)cls[l][i - p.base[l]] + 128];
           if (q >= qlo && q <= qhi) {
             int pos = atomicAdd(&s_n, 1);
             keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)i;
@@ -915,6 +921,7 @@ struct vbt_model {
   int* out_counts = nullptr;
   float* d_anchors = nullptr;
   unsigned char* d_luts = nullptr;   // post-process tables (see PostArgs)
+  std::vector<float> post_tables_host;   // scores indexed by rank byte + 128
   std::vector<Step> steps;      // execution list (after fusion + autotuning)
   std::vector<Group> groups;
   std::vector<Step> op_steps;   // one per graph op (weights live here)
@@ -2209,10 +2216,9 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       p.A = m->hdr.num_anchors;
       p.max_det = m->hdr.max_detections;
       p.iou_thr = m->hdr.nms_iou_threshold;
-      const float* lut = (const float*)(m->blob.data() + op.aux2_off);
-      int qmin = 128;
+      int qmin = 128;   // in rank bytes
       for (int q = 127; q >= -128; q--)
-        if (lut[q + 128] >= m->hdr.nms_score_threshold) qmin = q; else break;
+        if (m->post_tables_host[q + 128] >= m->hdr.nms_score_threshold) qmin = q; else break;
       p.qmin = qmin;
       postprocess_kernel<<<dim3((unsigned)B), 256, 0, st>>>(p, boxes, scores, classes, counts);
       break;
@@ -2521,7 +2527,23 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
       std::vector<unsigned char> lut(m->blob.data() + op.aux2_off, m->blob.data() + op.aux2_off + VBT_POST_TABLE_BYTES);
       const float* sv = (const float*)(lut.data() + 6144);
       if (sv[0] != sv[1] || sv[2] != sv[3]) { set_error("post-process: y_scale != x_scale or h_scale != w_scale"); return fail(VBT_ERR_ARG); }
-      if ((rc = upload(m, an, &m->d_anchors)) || (rc = upload(m, lut, &m->d_luts))) return fail(rc);
+      // device tables: scores re-indexed by rank byte, decode tables, class byte -> rank byte
+      std::vector<unsigned char> dev(1024 + 2048 + 2048 + 256, 0);
+      const float* score = (const float*)lut.data();
+      float* score_by_rank = (float*)dev.data();
+      signed char* rank = (signed char*)(dev.data() + 5120);
+      for (int q = 1; q < 256; q++)
+        if (score[q] < score[q - 1]) { set_error("post-process: score table is not monotone"); return fail(VBT_ERR_ARG); }
+      int r = 127;   // highest class byte gets rank 127; a strictly lower score steps the rank down
+      for (int q = 255; q >= 0; q--) {
+        if (q < 255 && score[q] != score[q + 1]) r--;
+        rank[q] = (signed char)r;
+        score_by_rank[r + 128] = score[q];
+      }
+      for (int i = -128; i < r; i++) score_by_rank[i + 128] = -1.0f;   // unused rank bytes: below every threshold
+      memcpy(dev.data() + 1024, lut.data() + 2048, 4096);
+      if ((rc = upload(m, an, &m->d_anchors)) || (rc = upload(m, dev, &m->d_luts))) return fail(rc);
+      m->post_tables_host.assign(score_by_rank, score_by_rank + 256);
     }
   {
     const char* ns = getenv("VBT_SUBSTREAMS");
