@@ -166,26 +166,74 @@ __device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_
 #include "stem_block.h"
 #include "image_block.h"
 #include "node_chain.h"
+#include "expdw_block.h"
 
 // ------------------------------------------------------------------------------------------
-// pointwise conv, variant A: K <= 256, activations of 16*MS pixels stay in registers while the
-// wave walks over the output-channel blocks.  wp = packed weights [nb][ks][t][lane] x 8 bytes.
+// pointwise conv on the gfx950 double-rate int8 MFMA (v_mfma_i32_16x16x64_i8: same 16 issue cycles as the legacy
+// 16x16x32 form for twice the K; measured in tools/probes).  A operand = packed weights, B operand = 16 input channels
+// of one pixel per lane (one 16-byte load).  K is padded to a multiple of 64 with zero weights: the activation bytes
+// read beyond a pixel's K channels (the next pixel, or the arena slack) multiply zeros.
+// wp = packed weights [nb][ks][t][lane] x 16 bytes (pack_weights64).
+// Epilogue: requantisation, optionally followed by the block's residual ADD (integer, XNNPACK qs8-vadd) with `res`.
 // ------------------------------------------------------------------------------------------
+struct ResArgs {
+  const int8_t* res;  // nullptr: no residual; else the second ADD input, same [M][N] layout as the output
+  AddQ q;
+};
+__device__ __forceinline__ void store_tile_r(const v4i acc[4], const Epi& e, const ResArgs& ra, int8_t* __restrict__ out, long m, int N,
+                                             int nb, int g) {
+  int c0 = nb * 64 + 16 * g;
+  if (c0 >= N) return;
+  unsigned d[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    int4 b = *(const int4*)(e.bias + c0 + 4 * t);
+    float4 mu = *(const float4*)(e.mult + c0 + 4 * t);
+    d[t] = rq_pack_i(acc[t], b, mu, e.rq);
+  }
+  if (ra.res) {   // N % 8 == 0 for every residual block
+    const int8_t* r = ra.res + m * N + c0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (c0 + 4 * t < N) d[t] = addq4(d[t], *(const unsigned*)(r + 4 * t), ra.q);
+  }
+  int8_t* o = out + m * N + c0;
+  if ((N & 15) == 0) {
+    *(uint4*)o = make_uint4(d[0], d[1], d[2], d[3]);
+  } else if ((N & 3) == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (c0 + 4 * t < N) *(unsigned*)(o + 4 * t) = d[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (c0 + 4 * t + j < N) o[4 * t + j] = (int8_t)(d[t] >> (8 * j));
+  }
+}
+__device__ __forceinline__ v4i ld16(const int8_t* p) {  // 16 bytes, any 4-byte alignment
+  v4i v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+
+// variant A: K <= 256: the activations of 16*MS pixels stay in registers while the wave walks over the channel blocks
 template <int KS, int MS>
-__global__ __launch_bounds__(256) void pw_a_kernel(const int8_t* __restrict__ x, const long* __restrict__ wp, Epi e,
+__global__ __launch_bounds__(256) void pw_a_kernel(const int8_t* __restrict__ x, const v4i* __restrict__ wp, Epi e, ResArgs ra,
                                                    int8_t* __restrict__ out, long M, int K, int N, int NB,
                                                    int nb_per_y) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
   const long m0 = ((long)blockIdx.x * 4 + wave) * (16 * MS);
   if (m0 >= M) return;
-  long a[MS][KS];
+  v4i a[MS][KS];
 #pragma unroll
   for (int ms = 0; ms < MS; ms++) {
     long m = min(m0 + 16 * ms + r, M - 1);
-    const int8_t* p = x + m * K + 8 * g;
+    const int8_t* p = x + m * K + 16 * g;
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) a[ms][ks] = *(const long*)(p + 32 * ks);
+    for (int ks = 0; ks < KS; ks++) a[ms][ks] = ld16(p + 64 * ks);
   }
   const int nb0 = blockIdx.y * nb_per_y, nb1 = min(nb0 + nb_per_y, NB);
   for (int nb = nb0; nb < nb1; nb++) {
@@ -194,20 +242,20 @@ __global__ __launch_bounds__(256) void pw_a_kernel(const int8_t* __restrict__ x,
     for (int ms = 0; ms < MS; ms++)
 #pragma unroll
       for (int t = 0; t < 4; t++) acc[ms][t] = (v4i){0, 0, 0, 0};
-    const long* w = wp + (long)nb * KS * 4 * 64 + lane;
+    const v4i* w = wp + (long)nb * KS * 4 * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++)
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        long wv = w[(ks * 4 + t) * 64];
+        v4i wv = w[(ks * 4 + t) * 64];
 #pragma unroll
         for (int ms = 0; ms < MS; ms++)
-          acc[ms][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wv, a[ms][ks], acc[ms][t], 0, 0, 0);
+          acc[ms][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, a[ms][ks], acc[ms][t], 0, 0, 0);
       }
 #pragma unroll
     for (int ms = 0; ms < MS; ms++) {
       long m = m0 + 16 * ms + r;
-      if (m < M) store_tile(acc[ms], e, out, m, N, nb, g);
+      if (m < M) store_tile_r(acc[ms], e, ra, out, m, N, nb, g);
     }
   }
 }
@@ -215,7 +263,7 @@ __global__ __launch_bounds__(256) void pw_a_kernel(const int8_t* __restrict__ x,
 // variant B: large K, few output channels: accumulators for NBT channel blocks stay in registers
 // while the wave streams the K dimension of its 16 pixels.
 template <int NBT>
-__global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x, const long* __restrict__ wp, Epi e,
+__global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x, const v4i* __restrict__ wp, Epi e, ResArgs ra,
                                                    int8_t* __restrict__ out, long M, int K, int KS, int N, int NB) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
@@ -227,23 +275,23 @@ __global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x,
   for (int i = 0; i < NBT; i++)
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[i][t] = (v4i){0, 0, 0, 0};
-  const int8_t* p = x + min(m0 + r, M - 1) * K + 8 * g;
+  const int8_t* p = x + min(m0 + r, M - 1) * K + 16 * g;
 #pragma unroll 4
   for (int ks = 0; ks < KS; ks++) {  // unrolled so that the loads of several k-steps are in flight together
-    long av = *(const long*)(p + 32 * ks);
+    v4i av = ld16(p + 64 * ks);
 #pragma unroll
     for (int i = 0; i < NBT; i++) {
       int nb = min(nb0 + i, NB - 1);
-      const long* w = wp + ((long)(nb * KS + ks) * 4) * 64 + lane;
+      const v4i* w = wp + ((long)(nb * KS + ks) * 4) * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], av, acc[i][t], 0, 0, 0);
+      for (int t = 0; t < 4; t++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[t * 64], av, acc[i][t], 0, 0, 0);
     }
   }
   long m = m0 + r;
   if (m < M) {
 #pragma unroll
     for (int i = 0; i < NBT; i++)
-      if (nb0 + i < NB) store_tile(acc[i], e, out, m, N, nb0 + i, g);
+      if (nb0 + i < NB) store_tile_r(acc[i], e, ra, out, m, N, nb0 + i, g);
   }
 }
 
@@ -251,7 +299,7 @@ __global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x,
 // 16 pixels and split K in four; partial accumulators meet in LDS, then each wave requantises one 16-channel
 // tile of every 64-channel block.  Quarter-length serial K loop, 4x the workgroups of variant B.
 template <int NBT>
-__global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x, const long* __restrict__ wp, Epi e,
+__global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x, const v4i* __restrict__ wp, Epi e, ResArgs ra,
                                                    int8_t* __restrict__ out, long M, int K, int KS, int N, int NB) {
   __shared__ v4i red[4][NBT * 4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -263,18 +311,18 @@ __global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x,
   for (int i = 0; i < NBT; i++)
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[i][t] = (v4i){0, 0, 0, 0};
-  const int8_t* p = x + min(m0 + r, M - 1) * K + 8 * g;
+  const int8_t* p = x + min(m0 + r, M - 1) * K + 16 * g;
   const int per = (KS + 3) >> 2;
   const int k0 = wave * per, k1 = min(k0 + per, KS);
 #pragma unroll 3
   for (int ks = k0; ks < k1; ks++) {
-    long av = *(const long*)(p + 32 * ks);
+    v4i av = ld16(p + 64 * ks);
 #pragma unroll
     for (int i = 0; i < NBT; i++) {
       int nb = min(nb0 + i, NB - 1);
-      const long* w = wp + ((long)(nb * KS + ks) * 4) * 64 + lane;
+      const v4i* w = wp + ((long)(nb * KS + ks) * 4) * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], av, acc[i][t], 0, 0, 0);
+      for (int t = 0; t < 4; t++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[t * 64], av, acc[i][t], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -298,6 +346,7 @@ __global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x,
       int4 b = *(const int4*)(e.bias + c0);
       float4 mu = *(const float4*)(e.mult + c0);
       unsigned d = rq_pack_i(s, b, mu, e.rq);
+      if (ra.res && (N & 3) == 0) d = addq4(d, *(const unsigned*)(ra.res + m * N + c0), ra.q);
       int8_t* o = out + m * N + c0;
       if ((N & 3) == 0) *(unsigned*)o = d;
       else
@@ -853,16 +902,19 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_CHAIN, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_CHAIN, F_EXPDW, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
                                            "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node", "fused_heads_multi",
-                                           "fused_stem_block", "fused_bifpn_chain"};
+                                           "fused_stem_block", "fused_bifpn_chain", "fused_expand_dw"};
 
 struct Step {
   int op;       // index into ops
   int family;
   // conv
-  long* wp = nullptr;      // packed MFMA weights (device)
+  long* wp = nullptr;      // packed MFMA weights, 16x16x32 layout (device): stem kernel and the expand stage of the fused kernels
+  v4i* wp64 = nullptr;     // pointwise convs: 16x16x64 layout (pack_weights64)
+  int KS64 = 0;            // K-steps of 64
+  int res_op = -1;         // F_PW: the residual ADD evaluated in the epilogue (op = that ADD, p_op = the conv)
   long* wdm = nullptr;     // depthwise: matrix-pipe (diagonal-embedded) weights
   int* bdm = nullptr;      // depthwise: bias folded for raw int8 inputs, padded to 64
   float* mdm = nullptr;    // depthwise: multipliers padded to 64
@@ -885,6 +937,8 @@ struct Step {
   FusedArgs* d_multi = nullptr;
   // F_STEMBLK: stem -> depthwise -> project in one kernel (op = project op, e_op = stem op)
   StemBlockArgs sb;
+  // F_EXPDW: expand + depthwise on whole images, expanded channels split over workgroups (expdw_block.h; op = depthwise op)
+  ExpDwArgs xd;
   // F_MBCONV on a low-resolution map: per-chunk weight records of the whole-image kernel (data == nullptr: not built)
   ImageBundle ib = {nullptr, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -999,6 +1053,23 @@ static void pack_weights(const int8_t* w, int N, int K, int KS, int NB, const st
 }
 
 
+// 16x16x64 layout: [(nb*KS + ks)*4 + t][lane][16 bytes]; lane (i = lane&15, g = lane>>4) holds
+// W[cout = 64nb + 16(i>>2) + 4t + (i&3)][k = 64ks + 16g + j], zero beyond N / K.
+static void pack_weights64(const int8_t* w, int N, int K, int KS, int NB, std::vector<v4i>& out) {
+  out.assign((size_t)NB * KS * 4 * 64, (v4i){0, 0, 0, 0});
+  int8_t* o = (int8_t*)out.data();
+  for (int nb = 0; nb < NB; nb++)
+    for (int ks = 0; ks < KS; ks++)
+      for (int t = 0; t < 4; t++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int i = lane & 15, g = lane >> 4, co = 64 * nb + 16 * (i >> 2) + 4 * t + (i & 3);
+          for (int j = 0; j < 16; j++) {
+            const int k = 64 * ks + 16 * g + j;
+            o[((((size_t)(nb * KS + ks) * 4 + t) * 64 + lane) * 16) + j] = (co < N && k < K) ? w[(size_t)co * K + k] : 0;
+          }
+        }
+}
+
 // ---- fusion pass: MBConv (pw+relu6 -> dw -> pw [-> add]) and SeparableConv (dw -> pw) -> fused_block_kernel ----
 static void choose_tile(int OH, int OW, int KK, int S, bool expand, int* TXo, int* TYo) {
   double best = 1e300;
@@ -1043,7 +1114,6 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   a.tiles_y = (tout.h + a.TY - 1) / a.TY;
   a.nchunks = Cp / 64;
   a.zx = tin.zero_point;
-  const Step& ds = m->op_steps[d_op];
   const Step& ps = m->op_steps[p_op];
   if (expand) {
     const Step& es = m->op_steps[e_op];
@@ -1433,6 +1503,111 @@ static int make_stem_block(vbt_model* m, int si, Step* out) {
   return VBT_OK;
 }
 
+// ---- expand + depthwise on whole images (expdw_block.h) ----
+static int expdw_lds(const ExpDwArgs& a) {
+  const int HW = a.H * a.W, NPGo = (a.OH * a.OW + 15) / 16;
+  return ((HW * a.T0S + 15) & ~15) + a.PH * a.PW * XD_EST + NPGo * 16 * XD_EST;
+}
+static bool expdw_ok(const vbt_model* m, int e_op, int d_op) {
+  const OpRec& e = m->ops[e_op];
+  const OpRec& d = m->ops[d_op];
+  const TensorRec& tin = m->tensors[e.inputs[0]];
+  const TensorRec& tout = m->tensors[d.output];
+  const int KS64 = (tin.c + 63) / 64;
+  const bool shape = (d.k == 3 && d.stride == 1) || (d.k == 5 && (d.stride == 1 || d.stride == 2));
+  return shape && tin.h * tin.w <= 400 && tout.h * tout.w <= 400 && tin.c % 16 == 0 && tout.c % 16 == 0 && KS64 >= 2 && KS64 <= 3;
+}
+static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
+  const OpRec& eop = m->ops[e_op];
+  const OpRec& dop = m->ops[d_op];
+  const TensorRec& tin = m->tensors[eop.inputs[0]];
+  const TensorRec& te = m->tensors[eop.output];
+  const TensorRec& td = m->tensors[dop.output];
+  Step s;
+  s.family = F_EXPDW;
+  s.op = d_op;
+  s.e_op = e_op;
+  s.d_op = d_op;
+  ExpDwArgs& a = s.xd;
+  memset(&a, 0, sizeof(a));
+  a.H = tin.h; a.W = tin.w; a.Cin = tin.c; a.OH = td.h; a.OW = td.w; a.Ce = te.c;
+  a.pad_t = dop.pad_t; a.pad_l = dop.pad_l;
+  a.PH = std::max((a.OH - 1) * dop.stride + dop.k, a.pad_t + a.H);
+  a.PW = std::max((a.OW - 1) * dop.stride + dop.k, a.pad_l + a.W);
+  const int KS64 = (tin.c + 63) / 64, K = tin.c, Ce = te.c, nch = (Ce + 63) / 64, kk = dop.k * dop.k, KT = (kk + 3) / 4;
+  a.T0S = KS64 * 64 + 16;
+  a.nchunks = nch;
+  a.cpw = 1;
+  const int8_t* we = (const int8_t*)(m->blob.data() + eop.w_off);
+  const int32_t* bqe = (const int32_t*)(m->blob.data() + eop.b_off);
+  const float* mue = (const float*)(m->blob.data() + eop.m_off);
+  const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
+  const int32_t* bqd = (const int32_t*)(m->blob.data() + dop.b_off);
+  const float* mud = (const float*)(m->blob.data() + dop.m_off);
+  std::vector<v4i> pe((size_t)nch * KS64 * 4 * 64, (v4i){0, 0, 0, 0}), pd((size_t)nch * 4 * KT * 64, (v4i){0, 0, 0, 0});
+  std::vector<int> be(nch * 64, 0), bd(nch * 64, 0);
+  std::vector<float> me(nch * 64, 0.0f), md(nch * 64, 0.0f);
+  int8_t* o = (int8_t*)pe.data();
+  for (int c = 0; c < nch; c++)
+    for (int ks = 0; ks < KS64; ks++)
+      for (int t = 0; t < 4; t++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int i = lane & 15, g = lane >> 4, ch = 64 * c + 16 * t + i;
+          for (int j = 0; j < 16; j++) {
+            const int k = 64 * ks + 16 * g + j;
+            o[((((size_t)(c * KS64 + ks) * 4 + t) * 64 + lane) * 16) + j] = (ch < Ce && k < K) ? we[(size_t)ch * K + k] : 0;
+          }
+        }
+  int8_t* od = (int8_t*)pd.data();
+  for (int c = 0; c < nch; c++)
+    for (int cg = 0; cg < 4; cg++)
+      for (int mi = 0; mi < KT; mi++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int i = lane & 15, g = lane >> 4, ch = 64 * c + 16 * cg + i, tap = 4 * mi + g;
+          for (int j = 0; j < 16; j++)
+            od[((((size_t)(c * 4 + cg) * KT + mi) * 64 + lane) * 16) + j] = (tap < kk && j == i && ch < Ce) ? wd[(size_t)tap * Ce + ch] : 0;
+        }
+  for (int ch = 0; ch < Ce; ch++) {
+    long swe = 0, swd = 0;
+    for (int k = 0; k < K; k++) swe += we[(size_t)ch * K + k];
+    for (int t = 0; t < kk; t++) swd += wd[(size_t)t * Ce + ch];
+    be[ch] = (int)((long)bqe[ch] - (long)tin.zero_point * swe);
+    me[ch] = mue[ch];
+    bd[ch] = (int)((long)bqd[ch] - (long)te.zero_point * swd);
+    md[ch] = mud[ch];
+  }
+  v4i *dpe, *dpd;
+  int *dbe, *dbd;
+  float *dme, *dmd;
+  int rc;
+  if ((rc = upload(m, pe, &dpe)) || (rc = upload(m, pd, &dpd)) || (rc = upload(m, be, &dbe)) || (rc = upload(m, bd, &dbd)) ||
+      (rc = upload(m, me, &dme)) || (rc = upload(m, md, &dmd)))
+    return rc;
+  a.we = dpe; a.wd = dpd; a.be = dbe; a.bd = dbd; a.me = dme; a.md = dmd;
+  a.rqe = make_rq(te.zero_point, eop.act_min, eop.act_max);
+  a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max);
+  a.zeb = (unsigned)(te.zero_point & 255) * 0x01010101u;
+  s.lds_bytes = expdw_lds(a);
+  for (int oi : {e_op, d_op}) {
+    s.alg_bytes_per_frame += m->op_steps[oi].alg_bytes_per_frame;
+    s.weight_bytes += m->op_steps[oi].weight_bytes;
+    s.macs_per_frame += m->op_steps[oi].macs_per_frame;
+  }
+  *out = s;
+  return VBT_OK;
+}
+
+// the projection conv `p_op` with the block's residual ADD `a_op` = ADD(conv output, skip) evaluated in its epilogue
+static Step pw_with_residual(const vbt_model* m, int p_op, int a_op) {
+  Step s = m->op_steps[p_op];
+  s.op = a_op;
+  s.p_op = p_op;
+  s.res_op = a_op;
+  s.addq = m->op_steps[a_op].addq;
+  s.alg_bytes_per_frame += m->op_steps[a_op].alg_bytes_per_frame;
+  return s;
+}
+
 static int chain_nodes(vbt_model* m);
 static int fuse_plan(vbt_model* m) {
   const int no = (int)m->ops.size();
@@ -1575,6 +1750,14 @@ static int fuse_plan(vbt_model* m) {
       Alt unf;
       for (int k = 0; k < span; k++) unf.steps.push_back(m->op_steps[i + k]);
       g.alts.push_back(unf);
+      if (a_op >= 0 && fuse_sep && m->tensors[p.output].c % 8 == 0) {   // one kernel per conv, the residual ADD in the projection's epilogue
+        Alt ar;
+        ar.steps.push_back(m->op_steps[i]);
+        ar.steps.push_back(m->op_steps[i + 1]);
+        ar.steps.push_back(pw_with_residual(m, i + 2, a_op));
+        ar.hidden.push_back(p.output);
+        g.alts.push_back(ar);
+      }
       if (fuse_sep) {  // expand as its own kernel, dw+project(+add) fused
         Alt a2;
         a2.steps.push_back(m->op_steps[i]);
@@ -1599,6 +1782,26 @@ static int fuse_plan(vbt_model* m) {
           a3.hidden.push_back(d.output);
           if (a_op >= 0) a3.hidden.push_back(p.output);
           g.alts.push_back(a3);
+        }
+      }
+      if (fuse_mb && !(m->flags & VBT_MODEL_NO_EXPDW) && expdw_ok(m, i, i + 1)) {
+        // low-resolution blocks: expand + depthwise on whole images (channel-split grid), projection as a pointwise GEMM with
+        // the residual in its epilogue
+        Alt ax;
+        Step sx;
+        int rc = make_expdw(m, i, i + 1, &sx);
+        if (rc) return rc;
+        if (sx.lds_bytes <= 160 * 1024) {
+          ax.steps.push_back(sx);
+          ax.hidden.push_back(op.output);
+          if (a_op >= 0 && m->tensors[p.output].c % 8 == 0) {
+            ax.steps.push_back(pw_with_residual(m, i + 2, a_op));
+            ax.hidden.push_back(p.output);
+          } else {
+            ax.steps.push_back(m->op_steps[i + 2]);
+            if (a_op >= 0) ax.steps.push_back(m->op_steps[a_op]);
+          }
+          g.alts.push_back(ax);
         }
       }
     } else if (fuse_sep && sep_ok(i)) {
@@ -1819,6 +2022,12 @@ static int build_plan(vbt_model* m) {
         }
         int rc;
         if ((rc = upload(m, wp, &s.wp)) || (rc = upload(m, bias, &s.bias)) || (rc = upload(m, mult, &s.mult))) return rc;
+        if (!stem) {
+          s.KS64 = (K + 63) / 64;
+          std::vector<v4i> wp64;
+          pack_weights64(w, N, K, s.KS64, s.NB, wp64);
+          if ((rc = upload(m, wp64, &s.wp64))) return rc;
+        }
         s.weight_bytes = (double)N * K;
         s.macs_per_frame = out_el * K;
       }
@@ -1888,10 +2097,10 @@ static int build_plan(vbt_model* m) {
 }
 
 template <int KS>
-static void launch_pw_a(int MS, dim3 grid, hipStream_t st, const int8_t* x, const long* wp, Epi e, int8_t* out, long M, int K,
+static void launch_pw_a(int MS, dim3 grid, hipStream_t st, const int8_t* x, const v4i* wp, Epi e, ResArgs ra, int8_t* out, long M, int K,
                         int N, int NB, int nb_per_y) {
-  if (MS == 2) pw_a_kernel<KS, 2><<<grid, 256, 0, st>>>(x, wp, e, out, M, K, N, NB, nb_per_y);
-  else pw_a_kernel<KS, 1><<<grid, 256, 0, st>>>(x, wp, e, out, M, K, N, NB, nb_per_y);
+  if (MS == 2) pw_a_kernel<KS, 2><<<grid, 256, 0, st>>>(x, wp, e, ra, out, M, K, N, NB, nb_per_y);
+  else pw_a_kernel<KS, 1><<<grid, 256, 0, st>>>(x, wp, e, ra, out, M, K, N, NB, nb_per_y);
 }
 
 // Launches one plan step for frames [boff, boff + B) of the batch (every tensor is batch-major).
@@ -1935,7 +2144,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
   classes += (size_t)boff * m->hdr.max_detections;
   counts += boff;
   int8_t* out = TP(op.output);
-  Epi e{s.bias, s.mult, to.zero_point, op.act_min, op.act_max, make_rq(to.zero_point, op.act_min, op.act_max)};
+  Epi e{s.bias, s.mult, to.zero_point, op.act_min, op.act_max, make_rq(to.zero_point, op.act_min, op.act_max)};   // (F_PW rebuilds it from its conv op)
   switch (s.family) {
     case F_STEM: {
       const TensorRec& ti = m->tensors[op.inputs[0]];
@@ -1945,11 +2154,17 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       break;
     }
     case F_PW: {
-      const TensorRec& ti = m->tensors[op.inputs[0]];
-      const int8_t* x = TP(op.inputs[0]);
-      long M = (long)B * to.h * to.w;
-      int K = ti.c, N = to.c;
-      if (s.KS <= 8) {
+      // op = the op whose output is written: the conv itself, or the residual ADD evaluated in its epilogue (res_op)
+      const OpRec& pop = m->ops[s.res_op >= 0 ? s.p_op : s.op];
+      const TensorRec& ti = m->tensors[pop.inputs[0]];
+      const TensorRec& tpo = m->tensors[pop.output];
+      const int8_t* x = TP(pop.inputs[0]);
+      e = Epi{s.bias, s.mult, tpo.zero_point, pop.act_min, pop.act_max, make_rq(tpo.zero_point, pop.act_min, pop.act_max)};
+      ResArgs ra{nullptr, s.addq};
+      if (s.res_op >= 0) ra.res = TP(m->ops[s.res_op].inputs[1]);   // ADD(conv output, skip): planner guarantees the order
+      long M = (long)B * tpo.h * tpo.w;
+      int K = ti.c, N = tpo.c;
+      if (s.KS64 <= 4) {
         int MS = s.variant >= 0 ? (s.variant & 1) + 1 : (M >= 32768 ? 2 : 1);
         long waves = (M + 16 * MS - 1) / (16 * MS);
         unsigned gx = (unsigned)((waves + 3) / 4);
@@ -1958,21 +2173,17 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         int nb_per_y = (s.NB + ysplit - 1) / ysplit;
         ysplit = (s.NB + nb_per_y - 1) / nb_per_y;
         dim3 grid(gx, ysplit);
-        switch (s.KS) {
-          case 1: launch_pw_a<1>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
-          case 2: launch_pw_a<2>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
-          case 3: launch_pw_a<3>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
-          case 4: launch_pw_a<4>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
-          case 5: launch_pw_a<5>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
-          case 6: launch_pw_a<6>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
-          case 7: launch_pw_a<7>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
-          default: launch_pw_a<8>(MS, grid, st, x, s.wp, e, out, M, K, N, s.NB, nb_per_y); break;
+        switch (s.KS64) {
+          case 1: launch_pw_a<1>(MS, grid, st, x, s.wp64, e, ra, out, M, K, N, s.NB, nb_per_y); break;
+          case 2: launch_pw_a<2>(MS, grid, st, x, s.wp64, e, ra, out, M, K, N, s.NB, nb_per_y); break;
+          case 3: launch_pw_a<3>(MS, grid, st, x, s.wp64, e, ra, out, M, K, N, s.NB, nb_per_y); break;
+          default: launch_pw_a<4>(MS, grid, st, x, s.wp64, e, ra, out, M, K, N, s.NB, nb_per_y); break;
         }
       } else if (s.variant == 2) {  // split-K over the 4 waves of a workgroup
         int nbt = std::min(s.NB, 2);
         dim3 grid((unsigned)((M + 15) / 16), (unsigned)((s.NB + nbt - 1) / nbt));
-        if (nbt == 1) pw_c_kernel<1><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB);
-        else pw_c_kernel<2><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB);
+        if (nbt == 1) pw_c_kernel<1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+        else pw_c_kernel<2><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
       } else {
         long waves = (M + 15) / 16;
         unsigned gx = (unsigned)((waves + 3) / 4);
@@ -1981,10 +2192,10 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         if (gx < 128) nbt = 1;
         dim3 grid(gx, (s.NB + nbt - 1) / nbt);
         switch (nbt) {
-          case 1: pw_b_kernel<1><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB); break;
-          case 2: pw_b_kernel<2><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB); break;
-          case 3: pw_b_kernel<3><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB); break;
-          default: pw_b_kernel<4><<<grid, 256, 0, st>>>(x, s.wp, e, out, M, K, s.KS, N, s.NB); break;
+          case 1: pw_b_kernel<1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB); break;
+          case 2: pw_b_kernel<2><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB); break;
+          case 3: pw_b_kernel<3><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB); break;
+          default: pw_b_kernel<4><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB); break;
         }
       }
       break;
@@ -2192,6 +2403,33 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       node_chain_kernel<<<dim3((unsigned)B), NC_THREADS, s.lds_bytes, st>>>(s.d_multi, (int)s.members.size());
       break;
     }
+    case F_EXPDW: {
+      ExpDwArgs a = s.xd;
+      const OpRec& eop = m->ops[s.e_op];
+      const OpRec& dop = m->ops[s.d_op];
+      a.x = TP(eop.inputs[0]);
+      a.out = out;
+      a.cpw = s.variant > 0 ? s.variant : std::max(1, (a.nchunks * B + 511) / 512);   // default: about two workgroups per CU
+      const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
+      const int KS64 = (a.Cin + 63) / 64;
+      dim3 grid((unsigned)(B * ngroups));
+#define XD_LAUNCH(KK, S)                                                                                             \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    if (KS64 == 2) expdw_image_kernel<KK, S, 2><<<grid, XD_THREADS, s.lds_bytes, st>>>(a);                           \
+    else expdw_image_kernel<KK, S, 3><<<grid, XD_THREADS, s.lds_bytes, st>>>(a);                                     \
+  } while (0)
+      if (dop.k == 3 && dop.stride == 1) XD_LAUNCH(3, 1);
+      else if (dop.k == 5 && dop.stride == 1) XD_LAUNCH(5, 1);
+      else XD_LAUNCH(5, 2);
+#undef XD_LAUNCH
+      break;
+    }
     case F_STEMBLK: {
       StemBlockArgs a = s.sb;
       a.frames = frames;
@@ -2286,7 +2524,7 @@ static void autotune(vbt_model* m) {
           for (int r : {1, 2, 4, 8, 16})
             if (r <= m->tensors[op.output].h) cand.push_back(r);
           if (m->tensors[op.output].c % 8 == 0) { cand.push_back(100); cand.push_back(101); }
-        } else if (st.family == F_PW && st.KS <= 8) {
+        } else if (st.family == F_PW && st.KS64 <= 4) {
           cand = {0, 1};
         } else if (st.family == F_PW) {
           cand = {-1, 2};
@@ -2296,6 +2534,10 @@ static void autotune(vbt_model* m) {
           if (st.family == F_MBCONV && st.fa.nch3 > 0 && st.nbp <= 2 && st.fa.KSe >= 1 && st.fa.KSe <= 4) { cand.push_back(9); cand.push_back(11); }  // 48-channel chunks
         } else if (st.family == F_MULTI) {
           cand = {0, 1};
+        } else if (st.family == F_EXPDW) {
+          cand.clear();
+          for (int cpw : {1, 2, 3, 4, 6})
+            if (cpw <= st.xd.nchunks) cand.push_back(cpw);
         }
         double best = 1e30;
         int bestv = -1;

@@ -1,0 +1,133 @@
+// Low-resolution MBConv, first half: expand 1x1 + ReLU6 -> depthwise kxk as ONE kernel whose tile is the whole image
+// and whose grid splits the EXPANDED CHANNELS: workgroup (image b, channel group q) produces `cpw` 64-channel chunks of
+// the depthwise output for all pixels of image b.  The projection then runs as a plain pointwise GEMM over that tensor
+// (pw_*_kernel, residual ADD in its epilogue).
+//
+// Why this shape (maps of at most 20x20 pixels, blocks b6..b15 of Lite0):
+//   * the tile kernel (fused_block.h) recomputes the expand on every 64-pixel tile's halo: 1.9x (3x3) to 2.9x (5x5) the
+//     useful work on a 20x20 map, and its LDS tiles do not fit the 10x10 x 1152-channel blocks at all;
+//   * expand and depthwise are independent per channel, so splitting the channels over workgroups needs no reduction
+//     (the projection, which sums over channels, is the part that is NOT fused here) and fills the chip at batch 64:
+//     64 images x (7.5 .. 18 chunks / cpw) workgroups;
+//   * the expand runs on the real pixels only and lands in an LDS copy of the image bordered by its zero point, so SAME
+//     padding costs nothing; the 6x expanded tensor never reaches HBM, the depthwise output (1/k^2 of the MACs) does.
+// LDS:  T0 [H*W][T0S]      block input, all channels (K padded to 64-byte steps: the pad multiplies zero weights)
+//       E  [PH*PW][80]     one 64-channel chunk of the expanded tensor inside a border of its zero point
+//       D  [OH*OW (16-padded)][80]  one chunk of the depthwise output, copied out with 16-byte stores
+// 16 wavefronts.  Both stages run on the 16x16x64 int8 MFMA; wave w keeps the operands of 16-channel tile (w & 3) in
+// registers and walks the pixel groups (w >> 2) + 4i.  Depthwise on the matrix pipe as in fused_block.h, four taps per
+// instruction: out[c][p] = sum_t W'[c][(t,c')] X[(t,c')][p], W' = w[t][c] delta(c,c'), exact int32.
+// Arithmetic identical to the per-op kernels: same integer accumulations, same single-op float requantisation.
+#pragma once
+
+constexpr int XD_WAVES = 16, XD_THREADS = 64 * XD_WAVES;
+constexpr int XD_EST = 80;   // bytes per pixel of E and D rows (64 + 16: bank spread, 16-byte aligned)
+
+struct ExpDwArgs {
+  const int8_t* x;   // [B][H][W][Cin]
+  int8_t* out;       // [B][OH][OW][Ce]: the graph's depthwise output tensor
+  int H, W, Cin, OH, OW, Ce;
+  int PW, PH;        // bordered E image
+  int pad_t, pad_l;
+  int T0S;           // KS64 * 64 + 16
+  int nchunks, cpw;  // 64-channel chunks in all / per workgroup
+  const v4i* we;     // expand weights [chunk][ks][t][lane] x 16 B: row i of tile t = channel 64c + 16t + i, k = 64ks + 16g + j
+  const int* be;     // bias with the input zero point folded, padded to 64 * nchunks
+  const float* me;
+  Rq rqe;
+  unsigned zeb;      // zero point of the expanded tensor x4
+  const v4i* wd;     // depthwise [chunk][cg][m][lane] x 16 B: row i = channel 64c + 16cg + i, k = 16g + j -> tap 4m + g, diagonal j == i
+  const int* bd;     // bias with the expanded tensor's zero point folded
+  const float* md;
+  Rq rqd;
+};
+
+template <int KK, int S, int KS64>
+__global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xd_smem[];
+  constexpr int KT = (KK * KK + 3) / 4;   // depthwise MFMAs per unit: four taps each
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
+  const long b = blockIdx.x / ngroups;
+  const int grp = blockIdx.x - (int)b * ngroups;
+  const int HW = a.H * a.W, OHW = a.OH * a.OW;
+  const int NPGi = (HW + 15) >> 4, NPGo = (OHW + 15) >> 4;
+  unsigned char* T0 = xd_smem;
+  unsigned char* E = T0 + ((HW * a.T0S + 15) & ~15);
+  unsigned char* D = E + a.PH * a.PW * XD_EST;
+  const float rcp_w = 1.0f / (float)a.W, rcp_ow = 1.0f / (float)a.OW;
+
+  // ---- input image -> T0 (16-byte granules; Cin % 16 == 0), E <- zero point everywhere (the border keeps it) ----
+  {
+    const int ng = a.Cin >> 4;
+    const int8_t* xb = a.x + b * (long)HW * a.Cin;
+    for (int i = tid; i < HW * ng; i += XD_THREADS) {
+      const int p = i / ng, sg = i - p * ng;
+      *(uint4*)(T0 + p * a.T0S + 16 * sg) = *(const uint4*)(xb + (long)p * a.Cin + 16 * sg);
+    }
+    const uint4 z4 = make_uint4(a.zeb, a.zeb, a.zeb, a.zeb);
+    for (int i = tid; i < a.PH * a.PW * (XD_EST / 16); i += XD_THREADS) *(uint4*)(E + 16 * i) = z4;
+  }
+  const int tq = wave & 3;   // this wave's 16-channel tile of the chunk, in both stages
+  // depthwise lane geometry: lane (r, g) reads, for MFMA m, the 16 channels of tile tq at input pixel
+  // (oy*S + ty, ox*S + tx) with tap 4m + g = ty*KK + tx (taps past the kernel re-read a valid one: zero weights)
+  int tapoff[KT];
+#pragma unroll
+  for (int m = 0; m < KT; m++) {
+    const int tap = min(4 * m + g, KK * KK - 1);
+    tapoff[m] = ((tap / KK) * a.PW + (tap % KK)) * XD_EST;
+  }
+  const int c_first = grp * a.cpw, c_last = min(c_first + a.cpw, a.nchunks);
+  __syncthreads();
+  for (int c = c_first; c < c_last; c++) {
+    // ---- stage E: expand chunk c on the real pixels; unit = (pixel group, tile tq) ----
+    {
+      const v4i* w = a.we + ((long)c * KS64 * 4 + tq) * 64 + lane;
+      v4i wreg[KS64];
+#pragma unroll
+      for (int ks = 0; ks < KS64; ks++) wreg[ks] = w[ks * 4 * 64];
+      const int4 eb = *(const int4*)(a.be + c * 64 + 16 * tq + 4 * g);
+      const float4 em = *(const float4*)(a.me + c * 64 + 16 * tq + 4 * g);
+      for (int pg = wave >> 2; pg < NPGi; pg += XD_WAVES / 4) {
+        const int p = pg * 16 + r, pc = min(p, HW - 1);
+        v4i acc = v4i_from(eb);
+        const unsigned char* brow = T0 + pc * a.T0S + 16 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS64; ks++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[ks], *(const v4i*)(brow + 64 * ks), acc, 0, 0, 0);
+        if (p < HW) {
+          const int py = fdiv_small(p, rcp_w), px = p - py * a.W;
+          *(unsigned*)(E + ((py + a.pad_t) * a.PW + px + a.pad_l) * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, em, a.rqe);
+        }
+      }
+    }
+    __syncthreads();   // E complete; the previous chunk's D has been copied out (that copy precedes this barrier)
+    // ---- stage D: depthwise on chunk c; unit = (output pixel group, channel tile tq) ----
+    {
+      const v4i* w = a.wd + ((long)(c * 4 + tq) * KT) * 64 + lane;
+      v4i wreg[KT];
+#pragma unroll
+      for (int m = 0; m < KT; m++) wreg[m] = w[m * 64];
+      const int4 bq = *(const int4*)(a.bd + c * 64 + 16 * tq + 4 * g);
+      const float4 mu = *(const float4*)(a.md + c * 64 + 16 * tq + 4 * g);
+      for (int pg = wave >> 2; pg < NPGo; pg += XD_WAVES / 4) {
+        const int slot = pg * 16 + r, sc = min(slot, OHW - 1);
+        const int oy = fdiv_small(sc, rcp_ow), ox = sc - oy * a.OW;
+        const unsigned char* pb = E + ((oy * S) * a.PW + ox * S) * XD_EST + 16 * tq;
+        v4i acc = v4i_from(bq);
+#pragma unroll
+        for (int m = 0; m < KT; m++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[m], *(const v4i*)(pb + tapoff[m]), acc, 0, 0, 0);
+        *(unsigned*)(D + slot * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, mu, a.rqd);
+      }
+    }
+    __syncthreads();   // D complete, E free for the next chunk's expand
+    // ---- stage O: D -> the depthwise output tensor, 16 bytes per lane, only the chunk's real channels ----
+    {
+      const int nv = min(64, a.Ce - 64 * c) >> 4;   // 16-byte parts of this chunk (Ce % 16 == 0)
+      int8_t* ob = a.out + b * (long)OHW * a.Ce + 64 * c;
+      for (int i = tid; i < OHW * nv; i += XD_THREADS) {
+        const int slot = i / nv, part = i - slot * nv;
+        *(uint4*)(ob + (long)slot * a.Ce + 16 * part) = *(const uint4*)(D + slot * XD_EST + 16 * part);
+      }
+    }
+  }
+}
