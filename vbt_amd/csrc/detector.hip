@@ -212,6 +212,53 @@ __device__ __forceinline__ void store_tile_r(const v4i acc[4], const Epi& e, con
         if (c0 + 4 * t + j < N) o[4 * t + j] = (int8_t)(d[t] >> (8 * j));
   }
 }
+// epilogue operands of one lane's 16 output channels (bias, multipliers, residual bytes): requested BEFORE the K loop so
+// that their latency overlaps the weight / activation streams instead of following the last MFMA
+struct EpiRegs {
+  int4 b[4];
+  float4 mu[4];
+  unsigned res[4];
+};
+__device__ __forceinline__ void load_epi(EpiRegs& er, const Epi& e, const ResArgs& ra, long m, int N, int nb, int g) {
+  const int c0 = min(nb * 64 + 16 * g, ((N + 15) & ~15) - 16);   // (bias / mult arrays are padded to 64-channel blocks)
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    er.b[t] = *(const int4*)(e.bias + c0 + 4 * t);
+    er.mu[t] = *(const float4*)(e.mult + c0 + 4 * t);
+    er.res[t] = 0u;
+  }
+  if (ra.res) {
+    const int8_t* r = ra.res + m * N + nb * 64 + 16 * g;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (nb * 64 + 16 * g + 4 * t < N) er.res[t] = *(const unsigned*)(r + 4 * t);
+  }
+}
+__device__ __forceinline__ void store_tile_e(const v4i acc[4], const EpiRegs& er, const Epi& e, const ResArgs& ra, int8_t* __restrict__ out,
+                                             long m, int N, int nb, int g) {
+  int c0 = nb * 64 + 16 * g;
+  if (c0 >= N) return;
+  unsigned d[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    d[t] = rq_pack_i(acc[t], er.b[t], er.mu[t], e.rq);
+    if (ra.res) d[t] = addq4(d[t], er.res[t], ra.q);
+  }
+  int8_t* o = out + m * N + c0;
+  if ((N & 15) == 0) {
+    *(uint4*)o = make_uint4(d[0], d[1], d[2], d[3]);
+  } else if ((N & 3) == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (c0 + 4 * t < N) *(unsigned*)(o + 4 * t) = d[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (c0 + 4 * t + j < N) o[4 * t + j] = (int8_t)(d[t] >> (8 * j));
+  }
+}
 __device__ __forceinline__ v4i ld16(const int8_t* p) {  // 16 bytes, any 4-byte alignment
   v4i v;
   __builtin_memcpy(&v, p, 16);
@@ -276,6 +323,9 @@ __global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x,
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[i][t] = (v4i){0, 0, 0, 0};
   const int8_t* p = x + min(m0 + r, M - 1) * K + 16 * g;
+  EpiRegs er[NBT];
+#pragma unroll
+  for (int i = 0; i < NBT; i++) load_epi(er[i], e, ra, min(m0 + r, M - 1), N, min(nb0 + i, NB - 1), g);
 #pragma unroll 4
   for (int ks = 0; ks < KS; ks++) {  // unrolled so that the loads of several k-steps are in flight together
     v4i av = ld16(p + 64 * ks);
@@ -291,7 +341,7 @@ __global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x,
   if (m < M) {
 #pragma unroll
     for (int i = 0; i < NBT; i++)
-      if (nb0 + i < NB) store_tile_r(acc[i], e, ra, out, m, N, nb0 + i, g);
+      if (nb0 + i < NB) store_tile_e(acc[i], er[i], e, ra, out, m, N, nb0 + i, g);
   }
 }
 
@@ -312,6 +362,17 @@ __global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x,
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[i][t] = (v4i){0, 0, 0, 0};
   const int8_t* p = x + min(m0 + r, M - 1) * K + 16 * g;
+  // this wave's epilogue operands (tile t = wave of every block), requested before the K loop
+  int4 eb[NBT];
+  float4 em[NBT];
+  unsigned eres[NBT];
+#pragma unroll
+  for (int i = 0; i < NBT; i++) {
+    const int c0 = min((nb0 + i) * 64 + 16 * g + 4 * wave, NB * 64 - 4);
+    eb[i] = *(const int4*)(e.bias + c0);
+    em[i] = *(const float4*)(e.mult + c0);
+    eres[i] = (ra.res && (N & 3) == 0 && c0 < N) ? *(const unsigned*)(ra.res + min(m0 + r, M - 1) * N + c0) : 0u;
+  }
   const int per = (KS + 3) >> 2;
   const int k0 = wave * per, k1 = min(k0 + per, KS);
 #pragma unroll 3
@@ -343,10 +404,8 @@ __global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x,
         v4i o = red[w2][i * 4 + t][lane];
         s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
       }
-      int4 b = *(const int4*)(e.bias + c0);
-      float4 mu = *(const float4*)(e.mult + c0);
-      unsigned d = rq_pack_i(s, b, mu, e.rq);
-      if (ra.res && (N & 3) == 0) d = addq4(d, *(const unsigned*)(ra.res + m * N + c0), ra.q);
+      unsigned d = rq_pack_i(s, eb[i], em[i], e.rq);
+      if (ra.res && (N & 3) == 0) d = addq4(d, eres[i], ra.q);
       int8_t* o = out + m * N + c0;
       if ((N & 3) == 0) *(unsigned*)o = d;
       else
@@ -1210,6 +1269,7 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   const int TXp = (a.TX + 3) & ~3;
   const int NPh = ((TXp - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
   s.lds_bytes = ((NPh * a.T0S + 15) & ~15) + (expand ? NPh * FB_EST : 0) + 64 * FB_DST;
+  if (!expand && a.nchunks == 1 && s.nbp <= 2) s.lds_bytes += s.nbp * (4096 + 512);   // projection weights + bias / multipliers staged in LDS
   // accounting = compulsory traffic of the constituent graph ops
   std::vector<int> parts{e_op, d_op, p_op, a_op, sum_op};
   if (ns) for (int j = 0; j < ns->n; j++) parts.push_back(ns->rs_op[j]);
@@ -2347,6 +2407,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         const int TXp_ = (a.TX + 3) & ~3;
         const int NPh_ = ((TXp_ - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
         lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + (s.family == F_MBCONV ? NPh_ * FB_EST : 0) + 64 * FB_DST;
+        if (s.family != F_MBCONV && a.nchunks == 1 && s.nbp <= 2) lds_bytes += s.nbp * (4096 + 512);
         grid = dim3((unsigned)((long)B * a.tiles_x * a.tiles_y));
       }
       if (nt3) {  // 72-byte E rows (fused_block.h)

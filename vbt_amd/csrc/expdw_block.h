@@ -78,46 +78,58 @@ __global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
     tapoff[m] = ((tap / KK) * a.PW + (tap % KK)) * XD_EST;
   }
   const int c_first = grp * a.cpw, c_last = min(c_first + a.cpw, a.nchunks);
+  // Operand flow: every global load is requested one stage before its use, so no stage starts with an exposed L2 round trip:
+  // chunk c's expand operands arrive during the previous chunk's depthwise (the first ones during the image load above),
+  // its depthwise operands during its own expand.
+  v4i ew[KS64];
+  int4 eb;
+  float4 em;
+  {
+    const v4i* w = a.we + ((long)c_first * KS64 * 4 + tq) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS64; ks++) ew[ks] = w[ks * 4 * 64];
+    eb = *(const int4*)(a.be + c_first * 64 + 16 * tq + 4 * g);
+    em = *(const float4*)(a.me + c_first * 64 + 16 * tq + 4 * g);
+  }
   __syncthreads();
   for (int c = c_first; c < c_last; c++) {
-    // ---- stage E: expand chunk c on the real pixels; unit = (pixel group, tile tq) ----
+    v4i dwv[KT];
     {
-      const v4i* w = a.we + ((long)c * KS64 * 4 + tq) * 64 + lane;
-      v4i wreg[KS64];
+      const v4i* w = a.wd + ((long)(c * 4 + tq) * KT) * 64 + lane;
 #pragma unroll
-      for (int ks = 0; ks < KS64; ks++) wreg[ks] = w[ks * 4 * 64];
-      const int4 eb = *(const int4*)(a.be + c * 64 + 16 * tq + 4 * g);
-      const float4 em = *(const float4*)(a.me + c * 64 + 16 * tq + 4 * g);
-      for (int pg = wave >> 2; pg < NPGi; pg += XD_WAVES / 4) {
-        const int p = pg * 16 + r, pc = min(p, HW - 1);
-        v4i acc = v4i_from(eb);
-        const unsigned char* brow = T0 + pc * a.T0S + 16 * g;
+      for (int m = 0; m < KT; m++) dwv[m] = w[m * 64];
+    }
+    const int4 bq = *(const int4*)(a.bd + c * 64 + 16 * tq + 4 * g);
+    const float4 mu = *(const float4*)(a.md + c * 64 + 16 * tq + 4 * g);
+    // ---- stage E: expand chunk c on the real pixels; unit = (pixel group, tile tq) ----
+    for (int pg = wave >> 2; pg < NPGi; pg += XD_WAVES / 4) {
+      const int p = pg * 16 + r, pc = min(p, HW - 1);
+      v4i acc = v4i_from(eb);
+      const unsigned char* brow = T0 + pc * a.T0S + 16 * g;
 #pragma unroll
-        for (int ks = 0; ks < KS64; ks++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[ks], *(const v4i*)(brow + 64 * ks), acc, 0, 0, 0);
-        if (p < HW) {
-          const int py = fdiv_small(p, rcp_w), px = p - py * a.W;
-          *(unsigned*)(E + ((py + a.pad_t) * a.PW + px + a.pad_l) * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, em, a.rqe);
-        }
+      for (int ks = 0; ks < KS64; ks++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ew[ks], *(const v4i*)(brow + 64 * ks), acc, 0, 0, 0);
+      if (p < HW) {
+        const int py = fdiv_small(p, rcp_w), px = p - py * a.W;
+        *(unsigned*)(E + ((py + a.pad_t) * a.PW + px + a.pad_l) * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, em, a.rqe);
       }
     }
     __syncthreads();   // E complete; the previous chunk's D has been copied out (that copy precedes this barrier)
+    if (c + 1 < c_last) {   // next chunk's expand operands
+      const v4i* w = a.we + ((long)(c + 1) * KS64 * 4 + tq) * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS64; ks++) ew[ks] = w[ks * 4 * 64];
+      eb = *(const int4*)(a.be + (c + 1) * 64 + 16 * tq + 4 * g);
+      em = *(const float4*)(a.me + (c + 1) * 64 + 16 * tq + 4 * g);
+    }
     // ---- stage D: depthwise on chunk c; unit = (output pixel group, channel tile tq) ----
-    {
-      const v4i* w = a.wd + ((long)(c * 4 + tq) * KT) * 64 + lane;
-      v4i wreg[KT];
+    for (int pg = wave >> 2; pg < NPGo; pg += XD_WAVES / 4) {
+      const int slot = pg * 16 + r, sc = min(slot, OHW - 1);
+      const int oy = fdiv_small(sc, rcp_ow), ox = sc - oy * a.OW;
+      const unsigned char* pb = E + ((oy * S) * a.PW + ox * S) * XD_EST + 16 * tq;
+      v4i acc = v4i_from(bq);
 #pragma unroll
-      for (int m = 0; m < KT; m++) wreg[m] = w[m * 64];
-      const int4 bq = *(const int4*)(a.bd + c * 64 + 16 * tq + 4 * g);
-      const float4 mu = *(const float4*)(a.md + c * 64 + 16 * tq + 4 * g);
-      for (int pg = wave >> 2; pg < NPGo; pg += XD_WAVES / 4) {
-        const int slot = pg * 16 + r, sc = min(slot, OHW - 1);
-        const int oy = fdiv_small(sc, rcp_ow), ox = sc - oy * a.OW;
-        const unsigned char* pb = E + ((oy * S) * a.PW + ox * S) * XD_EST + 16 * tq;
-        v4i acc = v4i_from(bq);
-#pragma unroll
-        for (int m = 0; m < KT; m++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[m], *(const v4i*)(pb + tapoff[m]), acc, 0, 0, 0);
-        *(unsigned*)(D + slot * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, mu, a.rqd);
-      }
+      for (int m = 0; m < KT; m++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(dwv[m], *(const v4i*)(pb + tapoff[m]), acc, 0, 0, 0);
+      *(unsigned*)(D + slot * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, mu, a.rqd);
     }
     __syncthreads();   // D complete, E free for the next chunk's expand
     // ---- stage O: D -> the depthwise output tensor, 16 bytes per lane, only the chunk's real channels ----

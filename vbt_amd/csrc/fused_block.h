@@ -109,6 +109,13 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   // free at stride 1, 2-way at stride 2; 80 bytes gives 2-way / 4-way) and less LDS per workgroup
   constexpr int EST = (EXPAND && NT == 3) ? 72 : FB_EST;
   unsigned char* D = E + (EXPAND ? ((NPh * EST + 15) & ~15) : 0);
+  // SeparableConv / node / head tiles whose depthwise input is ONE 64-channel chunk (BiFPN width 64): the projection
+  // weights and its bias / multipliers are copied into LDS while the input tile loads, so the projection and the epilogue
+  // start from LDS instead of from two more exposed L2 round trips (these kernels are latency chains, not bandwidth)
+  bool stage_p = false;
+  if constexpr (!EXPAND && NBP <= 2) stage_p = a.nchunks == 1;
+  unsigned char* WPS = D + 64 * FB_DST;          // [NBP][2][4][64] x 8 B
+  unsigned char* BPS = WPS + NBP * 4096;         // bias int[NBP*64] | mult float[NBP*64]
 
   // ---- stage L: input halo tile -> LDS ----
   bool summed = false;
@@ -211,6 +218,11 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       while (hx >= HWx) { hx -= HWx; hy++; }
     }
     }
+  }
+  if (stage_p) {
+    for (int i = tid; i < NBP * 256; i += 256) *(uint4*)(WPS + 16 * i) = *(const uint4*)((const unsigned char*)a.wp + 16 * (long)i);
+    if (tid < NBP * 16) *(uint4*)(BPS + 16 * tid) = *(const uint4*)((const unsigned char*)a.bp + 16 * tid);
+    else if (tid < NBP * 32) *(uint4*)(BPS + 16 * tid) = *(const uint4*)((const unsigned char*)a.mp + 16 * (tid - NBP * 16));
   }
   // which of this wave's halo pixel groups hold out-of-image pixels (expand epilogue), bit i <-> pg = wave + 4i
   const int NPG = (NPh + 15) >> 4;
@@ -443,9 +455,15 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       long bv = *(const long*)(D + (wave * 16 + r) * FB_DST + 32 * k2 + 8 * g);
 #pragma unroll
       for (int nb = 0; nb < NBP; nb++) {
-        const long* w = (NT == 3 ? a.wp3 + ((long)(nb * a.KSp3 + 2 * c + k2) * 4) * 64 : a.wp + ((long)(nb * a.KSp + 2 * c + k2) * 4) * 64) + lane;
+        if (stage_p) {
+          const long* w = (const long*)WPS + ((nb * 2 + k2) * 4) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[nb][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], bv, acc[nb][t], 0, 0, 0);
+          for (int t = 0; t < 4; t++) acc[nb][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], bv, acc[nb][t], 0, 0, 0);
+        } else {
+          const long* w = (NT == 3 ? a.wp3 + ((long)(nb * a.KSp3 + 2 * c + k2) * 4) * 64 : a.wp + ((long)(nb * a.KSp + 2 * c + k2) * 4) * 64) + lane;
+#pragma unroll
+          for (int t = 0; t < 4; t++) acc[nb][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(w[t * 64], bv, acc[nb][t], 0, 0, 0);
+        }
       }
     }
     if (!EXPAND && c + 1 < nch) __syncthreads();  // D is rewritten by the next chunk's depthwise
@@ -465,8 +483,15 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       unsigned d[4];
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        int4 bb = *(const int4*)(a.bp + c0 + 4 * t);
-        float4 mu = *(const float4*)(a.mp + c0 + 4 * t);
+        int4 bb;
+        float4 mu;
+        if (stage_p) {
+          bb = *(const int4*)(BPS + 4 * (c0 + 4 * t));
+          mu = *(const float4*)(BPS + NBP * 256 + 4 * (c0 + 4 * t));
+        } else {
+          bb = *(const int4*)(a.bp + c0 + 4 * t);
+          mu = *(const float4*)(a.mp + c0 + 4 * t);
+        }
         unsigned dq = rq_pack_i(acc[nb][t], bb, mu, a.rqp);
         if (a.has_res) {   // Cin == Cout, a multiple of 8: the skip dword is in range whenever c0 + 4t < Cout
           const unsigned xs = *(const unsigned*)(skip + min(c0 + 4 * t, a.Cin - 4));
@@ -494,7 +519,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 
 
 template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4>
-__global__ __launch_bounds__(256) void fused_block_kernel(FusedArgs a) {
+#ifndef FB_MINW
+#define FB_MINW 1
+#endif
+__global__ __launch_bounds__(256, FB_MINW) void fused_block_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem_dyn[];
   fused_block_body<KK, S, NBP, EXPAND, MDW, KSE, NT>(a, blockIdx.x, fb_smem_dyn);
 }
@@ -506,7 +534,7 @@ struct MultiTiles {
   int start[13];  // start[p] = first workgroup of problem p, start[n] = grid size
 };
 template <int KK, int S, int NBP, bool EXPAND, bool MDW>
-__global__ __launch_bounds__(256) void fused_block_multi_kernel(const FusedArgs* __restrict__ args, MultiTiles mt) {
+__global__ __launch_bounds__(256, FB_MINW) void fused_block_multi_kernel(const FusedArgs* __restrict__ args, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem_dyn[];
   int p = 0;
 #pragma unroll
