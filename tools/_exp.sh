@@ -1,11 +1,19 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-export VBT_PLAN_FILE=$PWD/profiles/plan_lite0
-rocprofv3 -L > gpurun_out/counters_list.txt 2>&1
-grep -o "SQ_[A-Z_0-9]*" gpurun_out/counters_list.txt | sort -u | tr '\n' ' ' | head -c 6000
-echo
-B="bench.py --steps 6 --warmup 2 --cpu-frames 0 --no-extras --no-roofline"
-VBT_PIPELINE_DEPTH=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d gpurun_out/pmc_a -o a --output-format csv -- python3 $B > /dev/null 2> gpurun_out/pmc_a.err
-VBT_PIPELINE_DEPTH=1 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d gpurun_out/pmc_b -o b --output-format csv -- python3 $B > /dev/null 2> gpurun_out/pmc_b.err
-VBT_PIPELINE_DEPTH=1 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVE_DEP_WAIT SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_IFETCH -d gpurun_out/pmc_c -o c --output-format csv -- python3 $B > /dev/null 2> gpurun_out/pmc_c.err
-ls gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c; tail -3 gpurun_out/pmc_c.err
+python - <<'PY'
+import torch, time
+x = torch.empty(64*320*320*3, dtype=torch.uint8).pin_memory()
+d = torch.empty_like(x, device='cuda')
+s = torch.cuda.Stream()
+for n in (1, 3):
+    torch.cuda.synchronize(); t=time.perf_counter()
+    with torch.cuda.stream(s):
+        for i in range(20): d.copy_(x, non_blocking=True)
+    torch.cuda.synchronize(); dt=time.perf_counter()-t
+    print('H2D pinned 19.66 MB x20:', dt/20*1e3, 'ms each', x.numel()*20/dt/1e9, 'GB/s')
+y = torch.empty(64*320*320*3, dtype=torch.uint8)
+torch.cuda.synchronize(); t=time.perf_counter()
+for i in range(5): d.copy_(y)
+torch.cuda.synchronize(); dt=time.perf_counter()-t
+print('H2D pageable:', y.numel()*5/dt/1e9, 'GB/s')
+PY
+python bench.py --steps 20 --warmup 5 --cpu-frames 0 --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), d['value_h2d_inclusive'], d['h2d_inclusive']['ms_per_step'], d['splits']['detect_only']['frames_per_s'])"
