@@ -298,7 +298,7 @@ def extra_measurements(torch, pipe, frames, frames_np, n, K, U, fbytes, stream, 
     host = torch.from_numpy(frames_np[:Uh]).pin_memory()                       # [Uh, n, S, S, 3]
     rows_host = torch.empty(n * pipe.tracker.rows_cap * 64, dtype=torch.uint8).pin_memory()
     reset()
-    for i in range(3):
+    for i in range(2 * Uh):                     # every pinned slice once (first DMA from a pinned page is slow), twice for the staging ring
         pipe.step(host[i % Uh], stream)
     torch.cuda.synchronize()
     reset()

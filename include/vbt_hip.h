@@ -152,7 +152,9 @@ int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts
 
 /* Fused path: one frame per clip straight from vbt_detect_async's device outputs; applies the
  * detection threshold of reference odt.py:70-75 (score >= det_threshold). times_host [n_clips]; a negative time marks a
- * clip that has no frame in this step (clips of different lengths batched together): its state is left untouched. */
+ * clip that has no frame in this step (clips of different lengths batched together): its state is left untouched.
+ * The host arrays are read during the call and travel in the kernel arguments (64 slots per launch): no host-to-device
+ * copy is enqueued, the caller may reuse them as soon as the call returns. */
 int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, const float* scores_dev,
                                        const int32_t* counts_dev, const double* times_host, float det_threshold,
                                        void* stream);
@@ -181,8 +183,10 @@ int vbt_tracker_rows(vbt_tracker* t, int clip, int64_t* id, double* cols7, int c
 int vbt_tracker_finish(vbt_tracker* t, double plate_diameter, double diff_threshold, double min_distance, void* stream);
 /* phases6 [P,6] = time_start,time_end,y_start,y_end,rom,type (reference Phase.py:16-22) */
 int vbt_tracker_phases(vbt_tracker* t, int clip, int32_t* best_id, double* phases6, int cap, int* P);
-/* The same for every clip at once (arrays of n_clips entries; phases6 is [n_clips][cap][6], rows beyond n_phases[c] are
- * not written): export ids, DataFrame row counts, phase counts and overflow flags in four device-to-host copies. */
+/* Clip close of every clip at once (arrays of n_clips entries; phases6 is [n_clips][cap][6], rows beyond n_phases[c] are
+ * not written): export ids, DataFrame row counts, phase counts and overflow flags are packed on the device into one
+ * block, fetched by ONE asynchronous copy into pinned memory and ONE synchronisation of the stream vbt_tracker_finish ran
+ * on (not of the device). */
 int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int32_t* n_phases, int32_t* overflow, double* phases6, int cap);
 /* DataFrame rows (reference track.py:227-234) of EVERY clip in one strided device-to-host copy on `stream` (which the
  * call synchronises): rows_host = [n_clips][cap] records of 64 bytes {int64 id; double time, x, y, dx, dy,

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 outputs of one measurement session (under gpurun_out/) into the committed artefacts under
-profiles/: r01_final_{summary.md,kernel_stats_depth1.csv,kernel_stats_depth3.csv,bench.json,traffic.json}.
-
-Expected inputs (see DESIGN.md section 5 for the commands that produce them):
-  gpurun_out/bench_final.json                        python bench.py
-  gpurun_out/prof_final/**/kernel_{trace,stats}.csv  rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --cpu-frames 0
-  gpurun_out/prof_final_d1/...                       same with VBT_PIPELINE_DEPTH=1
-  gpurun_out/pmc_fetchF, gpurun_out/pmc_writeF       rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (depth 1, --no-roofline)
+"""Turn the raw outputs of one measurement session (tools/profile_session.sh <tag>, under gpurun_out/<tag>/) into the
+committed artefacts under profiles/:
+  <tag>_bench.json, <tag>_bench_k20.json      the bench lines (defaults / the driver's --steps 20 --warmup 5)
+  <tag>_kernel_stats_depth{1,3}.csv           rocprofv3 --kernel-trace --stats summaries
+  <tag>_summary.md                            per-family kernel time, HBM traffic, instruction / wait counters
+  <tag>_counters.json                         what bench.py's `roofline` block reads: HBM bytes per launch per family and the
+                                              two counter-derived fractions BASELINE.json's north_star names
+usage: python tools/make_profile_summary.py r02 [out_tag]
+Peaks (MI355X_MICROARCH.md): HBM 8 TB/s spec; int8 MFMA 16x16x64 = 2x the bf16 rate = 16 cycles per instruction per SIMD,
+1024 SIMDs; SQ_* wave counters are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE in cycles.
 """
 import collections
 import csv
@@ -15,12 +17,14 @@ import json
 import shutil
 import sys
 
-FAM = (("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"), ("mbconv_image", "fused_mbconv"),
-       ("dw_tile", "dw_conv_f32acc"), ("dw_col", "dw_conv_f32acc"), ("dw_kernel", "dw_conv_f32acc"), ("pw_a", "pw_conv_mfma_i8"),
-       ("pw_b", "pw_conv_mfma_i8"), ("pw_c", "pw_conv_mfma_i8"), ("stem_kernel", "stem_conv_mfma_i8"), ("add_kernel", "add_requant"),
-       ("maxpool", "maxpool3x3s2"), ("resize_kernel", "resize_nn"), ("postprocess", "decode_nms"), ("tracker_from", "ocsort_step"),
-       ("analyze", "rep_analysis"), ("select_gather", "export_select"))
+FAM = (("expdw_image", "fused_expand_dw"), ("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"),
+       ("mbconv_image", "fused_mbconv"), ("dw_tile", "dw_conv"), ("dw_col", "dw_conv"), ("dw_kernel", "dw_conv"),
+       ("pw_a", "pw_conv_mfma_i8"), ("pw_b", "pw_conv_mfma_i8"), ("pw_c", "pw_conv_mfma_i8"), ("stem_kernel", "stem_conv_mfma_i8"),
+       ("add_kernel", "add_requant"), ("maxpool", "maxpool3x3s2"), ("resize_kernel", "resize_nn"), ("postprocess", "decode_nms"),
+       ("tracker_from", "ocsort_step"), ("analyze", "rep_analysis"), ("select_gather", "export_select"), ("pack_summary", "close_pack"))
 FIRST = "stem_block_kernel"        # first kernel of every forward
+HBM_PEAK = 8.0e12
+SIMDS, CLOCK = 1024, 2.4e9
 
 
 def fam(n):
@@ -40,9 +44,10 @@ def one(pattern):
     return g[0]
 
 
-def steady(dirn, nf=50, skip=5):
-    tr = sorted(csv.DictReader(open(one(f"gpurun_out/{dirn}/**/*kernel_trace.csv"))), key=lambda r: int(r["Dispatch_Id"]))
+def steady(d, nf=40):
+    tr = sorted(csv.DictReader(open(one(f"{d}/**/*kernel_trace.csv"))), key=lambda r: int(r["Dispatch_Id"]))
     idx = [i for i, r in enumerate(tr) if FIRST in r["Kernel_Name"]]
+    nf = min(nf, len(idx) - 1)
     st = tr[idx[-(nf + 1)]:idx[-1]]
     agg = collections.OrderedDict()
     for r in st:
@@ -54,58 +59,110 @@ def steady(dirn, nf=50, skip=5):
     return agg, nf, (t1 - t0) / nf / 1e6
 
 
-def counter_rows(d, counter):
-    rs = [r for r in csv.DictReader(open(one(f"gpurun_out/{d}/**/*counter_collection.csv"))) if r["Counter_Name"] == counter]
+def counters(d):
+    """{family: {counter: value per forward}} from the second-to-last complete forward of a --pmc pass"""
+    rs = list(csv.DictReader(open(one(f"{d}/**/*counter_collection.csv"))))
     rs.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ix = [i for i, r in enumerate(rs) if FIRST in r["Kernel_Name"]]
-    return rs[ix[-3]:ix[-2]]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rs if FIRST in r["Kernel_Name"]})
+    lo, hi = ids[-3], ids[-2]
+    out = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.Counter()
+    seen = set()
+    for r in rs:
+        di = int(r["Dispatch_Id"])
+        if lo <= di < hi:
+            f = fam(r["Kernel_Name"])
+            out[f][r["Counter_Name"]] += float(r["Counter_Value"])
+            if di not in seen:
+                seen.add(di)
+                launches[f] += 1
+    return out, launches
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
-    bench = json.loads(open("gpurun_out/bench_final.json").read().strip().splitlines()[-1])
-    json.dump(bench, open(f"profiles/{tag}_bench.json", "w"), indent=1)
-    shutil.copy(one("gpurun_out/prof_final/**/*kernel_stats.csv"), f"profiles/{tag}_kernel_stats_depth3.csv")
-    shutil.copy(one("gpurun_out/prof_final_d1/**/*kernel_stats.csv"), f"profiles/{tag}_kernel_stats_depth1.csv")
-    tr_agg = collections.OrderedDict()
-    for r in counter_rows("pmc_fetchF", "FETCH_SIZE"):
-        a = tr_agg.setdefault(fam(r["Kernel_Name"]), [0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
-    for r in counter_rows("pmc_writeF", "WRITE_SIZE"):
-        tr_agg.setdefault(fam(r["Kernel_Name"]), [0, 0.0, 0.0])[2] += float(r["Counter_Value"])
-    a3, nf, wall3 = steady("prof_final")
-    a1, _, wall1 = steady("prof_final_d1")
-    with open(f"profiles/{tag}_summary.md", "w") as f:
-        f.write(f"# {tag}: rocprofv3 on `python bench.py --steps 50 --warmup 5 --cpu-frames 0` (MI355X, 64 clips/step, plan = profiles/plan_lite0.b64.f0)\n\n")
-        f.write(f"Un-profiled bench.py (defaults): **{bench['value']:.0f} frames/s end-to-end, {bench['ms_per_step']:.3f} ms/step** (pipeline depth 3).\n")
-        f.write("Under `rocprofv3 --kernel-trace --stats` dispatches serialise, so the overlap between the forwards in flight is lost while "
-                f"profiling: trace wall per step {wall3:.3f} ms (depth 3) / {wall1:.3f} ms (`VBT_PIPELINE_DEPTH=1`).\n\n")
-        for title, agg, wall in (("depth 1 (one forward at a time; comparable with bench.py's isolated HIP-event pass)", a1, wall1),
-                                 ("depth 3 (bench.py default)", a3, wall3)):
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    out_tag = sys.argv[2] if len(sys.argv) > 2 else tag
+    src = f"gpurun_out/{tag}"
+    bench = json.loads(open(f"{src}/bench_default.json").read().strip().splitlines()[-1])
+    k20 = json.loads(open(f"{src}/bench_k20.json").read().strip().splitlines()[-1])
+    json.dump(bench, open(f"profiles/{out_tag}_bench.json", "w"), indent=1)
+    json.dump(k20, open(f"profiles/{out_tag}_bench_k20.json", "w"), indent=1)
+    shutil.copy(one(f"{src}/trace_d3/**/*kernel_stats.csv"), f"profiles/{out_tag}_kernel_stats_depth3.csv")
+    shutil.copy(one(f"{src}/trace_d1/**/*kernel_stats.csv"), f"profiles/{out_tag}_kernel_stats_depth1.csv")
+    a3, nf3, wall3 = steady(f"{src}/trace_d3")
+    a1, nf1, wall1 = steady(f"{src}/trace_d1")
+    cf, lf = counters(f"{src}/pmc_fetch")
+    cw, _ = counters(f"{src}/pmc_write")
+    ca, _ = counters(f"{src}/pmc_sqa")
+    cb, _ = counters(f"{src}/pmc_sqb")
+    fams = sorted(a1, key=lambda k: -a1[k][1])
+    hbm = {}
+    for k in fams:
+        fetch = 2.0 * cf[k].get("FETCH_SIZE", 0.0) * 1024       # gfx950: FETCH_SIZE reports half of a wide streaming read; KB units
+        write = cw[k].get("WRITE_SIZE", 0.0) * 1024
+        hbm[k] = (fetch, write)
+    us = {k: a1[k][1] / nf1 / 1e3 for k in fams}                  # kernel microseconds per forward (depth 1)
+    with open(f"profiles/{out_tag}_summary.md", "w") as f:
+        f.write(f"# {out_tag}: measurement session on one MI355X (64 clips per step, plan = profiles/plan_lite0.b64.f0, tools/profile_session.sh)\n\n")
+        f.write(f"Un-profiled `python bench.py` (defaults: 1000 steps): **{bench['value']:.0f} frames/s end-to-end, {bench['ms_per_step']:.3f} ms/step** "
+                f"(pipeline depth {bench['config'].get('pipeline_depth', 3)}); H2D-inclusive {bench.get('value_h2d_inclusive', 0):.0f} frames/s; "
+                f"detector only {bench['splits']['detect_only']['frames_per_s']:.0f} frames/s; OC-SORT step {bench['splits']['track_only']['us_per_step']:.1f} us per 64 clips.\n")
+        f.write(f"Driver-style `python bench.py --steps 20 --warmup 5`: **{k20['value']:.0f} frames/s, {k20['ms_per_step']:.3f} ms/step** "
+                f"(timed region: enqueue {k20['timed_region_ms']['enqueue']:.2f} ms, clip close incl. pipeline drain {k20['timed_region_ms']['clip_close']:.2f} ms).\n")
+        f.write("Under `rocprofv3 --kernel-trace` dispatches serialise, so the overlap between the forwards in flight is lost while profiling: "
+                f"trace wall per step {wall3:.3f} ms (depth 3) / {wall1:.3f} ms (`VBT_PIPELINE_DEPTH=1`).\n\n")
+        for title, agg, nf, wall in (("depth 1 (one forward at a time)", a1, nf1, wall1), ("depth 3 (bench.py default)", a3, nf3, wall3)):
             tot = sum(v[1] for v in agg.values())
             f.write(f"## kernel time, {title}\n\n| family | launches/step | avg us/launch | ms/step | % GPU time |\n|---|---|---|---|---|\n")
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"| {k} | {v[0]/nf:.1f} | {v[1]/v[0]/1e3:.2f} | {v[1]/nf/1e6:.4f} | {100*v[1]/tot:.1f} |\n")
             f.write(f"\nSum of kernel durations per step: {tot/nf/1e6:.3f} ms; trace wall per step: {wall:.3f} ms.\n\n")
-        rf = bench.get("roofline") or {}
-        dom = a1.get(rf.get("kernel"))
-        if dom:
-            f.write(f"bench.py HIP-event figure for the dominant family ({rf['kernel']}): {rf['avg_launch_us']:.1f} us/launch over "
-                    f"{rf['launches_per_step']} launches; rocprofv3 (depth 1): {dom[1]/dom[0]/1e3:.1f} us/launch.\n")
-        f.write("\n## HBM-side traffic of ONE forward (separate --pmc passes at depth 1; FETCH_SIZE x2 per the gfx950 note of "
-                "MI355X_MICROARCH.md, WRITE_SIZE as is; KB -> bytes x1024)\n\n| family | launches | fetch MB | write MB | total MB |\n|---|---|---|---|---|\n")
-        t2 = 0
-        for k, (n, fv, wv) in sorted(tr_agg.items(), key=lambda kv: -(2 * kv[1][1] + kv[1][2])):
-            hb = (2 * fv + wv) * 1024
-            t2 += hb
-            f.write(f"| {k} | {n} | {2*fv*1024/1e6:.1f} | {wv*1024/1e6:.1f} | {hb/1e6:.1f} |\n")
-        f.write(f"\nTotal {t2/1e6:.0f} MB per 64-frame forward = {t2/64/1e6:.1f} MB/frame, against 2450 MB (38.3 MB/frame) of "
-                "compulsory traffic of the unfused graph.\n")
-    json.dump({"plan": "profiles/plan_lite0.b64.f0", "batch": 64,
-               "families": {k: {"launches": v[0], "hbm_bytes_per_launch": (2 * v[1] + v[2]) * 1024 / v[0]} for k, v in tr_agg.items() if v[0]}},
-              open(f"profiles/{tag}_traffic.json", "w"), indent=1)
-    print(open(f"profiles/{tag}_summary.md").read())
+        f.write("## HBM-side traffic of ONE forward (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes at depth 1; FETCH_SIZE x2 per the gfx950 "
+                "note of MI355X_MICROARCH.md, WRITE_SIZE as is, KB -> bytes)\n\n| family | launches | fetch MB | write MB | total MB | kernel us | achieved GB/s | % of 8 TB/s |\n|---|---|---|---|---|---|---|---|\n")
+        tot_b = 0
+        for k in fams:
+            fb, wb = hbm[k]
+            tot_b += fb + wb
+            gbs = (fb + wb) / (us[k] * 1e-6) / 1e9 if us[k] else 0
+            f.write(f"| {k} | {lf[k]} | {fb/1e6:.1f} | {wb/1e6:.1f} | {(fb+wb)/1e6:.1f} | {us[k]:.1f} | {gbs:.0f} | {100*gbs*1e9/HBM_PEAK:.1f} |\n")
+        f.write(f"\nTotal {tot_b/1e6:.0f} MB per 64-frame forward = {tot_b/64/1e6:.1f} MB/frame, against 2450 MB (38.3 MB/frame, int8) of compulsory traffic "
+                "of the unfused graph (SURVEY.md 8d scaled to 1 byte per element).\n\n")
+        f.write("## SQ counters of ONE forward (two `--pmc` passes at depth 1; instruction counts in millions of wave-instructions; wave-state "
+                "counters as a share of SQ_WAVE_CYCLES)\n\n| family | VALU | SALU | LDS | VMEM_RD | MFMA | MFMA busy % of kernel | LDS bank conflict % | waves parked (WAIT_ANY) % | issue stall (WAIT_INST_ANY) % | issuing (ACTIVE_INST_ANY) % |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+        derived = {}
+        for k in fams:
+            b, a = cb[k], ca[k]
+            wc = a.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+            mfma_busy = b.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (us[k] * 1e-6 * CLOCK * SIMDS) if us[k] else 0.0
+            conf = b.get("SQ_LDS_BANK_CONFLICT", 0.0) / (b.get("SQ_LDS_IDX_ACTIVE", 0.0) or 1.0)
+            derived[k] = {"mfma_busy_frac": mfma_busy, "lds_bank_conflict_frac": conf, "valu_minsts": b.get("SQ_INSTS_VALU", 0.0) / 1e6,
+                          "wait_any_frac": a.get("SQ_WAIT_ANY", 0.0) / wc, "active_inst_frac": a.get("SQ_ACTIVE_INST_ANY", 0.0) / wc}
+            f.write(f"| {k} | {b.get('SQ_INSTS_VALU',0)/1e6:.2f} | {b.get('SQ_INSTS_SALU',0)/1e6:.2f} | {b.get('SQ_INSTS_LDS',0)/1e6:.2f} | "
+                    f"{b.get('SQ_INSTS_VMEM_RD',0)/1e6:.2f} | {b.get('SQ_INSTS_MFMA',0)/1e6:.2f} | {100*mfma_busy:.1f} | {100*conf:.1f} | "
+                    f"{100*a.get('SQ_WAIT_ANY',0)/wc:.1f} | {100*a.get('SQ_WAIT_INST_ANY',0)/wc:.1f} | {100*a.get('SQ_ACTIVE_INST_ANY',0)/wc:.1f} |\n")
+        valu = sum(cb[k].get("SQ_INSTS_VALU", 0.0) for k in fams)
+        f.write(f"\nVALU issue floor of the forward: {valu/1e6:.0f} M wave-instructions x 2..4 cycles / 1024 SIMDs / 2.4 GHz = "
+                f"{valu*2/SIMDS/CLOCK*1e3:.3f}..{valu*4/SIMDS/CLOCK*1e3:.3f} ms (two or more waves per SIMD issue every 2 cycles, one wave every 4).\n\n")
+        # the two fractions BASELINE.json's north_star names
+        dw_fams = [k for k in fams if k in ("dw_conv", "fused_expand_dw")]
+        pw = "pw_conv_mfma_i8"
+        f.write("## The two counter-derived fractions named by the north_star\n\n")
+        nstar = {}
+        for k in dw_fams + ["fused_mbconv"]:
+            fb, wb = hbm[k]
+            gbs = (fb + wb) / (us[k] * 1e-6)
+            nstar[f"{k}_hbm_frac"] = gbs / HBM_PEAK
+            f.write(f"* depthwise-bearing family `{k}`: {(fb+wb)/1e6:.1f} MB over {us[k]:.1f} us = {gbs/1e9:.0f} GB/s = **{100*gbs/HBM_PEAK:.1f} % of the 8 TB/s HBM peak**\n")
+        if pw in us:
+            nstar["pw_mfma_util"] = derived[pw]["mfma_busy_frac"]
+            macs = None
+            f.write(f"* pointwise convs `{pw}` (16x16x64 int8 MFMA): SQ_VALU_MFMA_BUSY_CYCLES {cb[pw].get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1e6:.1f} M over "
+                    f"{us[pw]:.1f} us x 2.4 GHz x 1024 SIMDs = **{100*derived[pw]['mfma_busy_frac']:.1f} % MFMA utilisation**\n")
+    json.dump({"plan": "profiles/plan_lite0.b64.f0", "batch": 64, "session": tag,
+               "families": {k: {"launches": lf[k], "hbm_bytes_per_launch": (hbm[k][0] + hbm[k][1]) / lf[k], "kernel_us_per_forward": us[k]} for k in fams if lf[k]},
+               "derived": {"per_family": derived, "north_star": nstar}},
+              open(f"profiles/{out_tag}_counters.json", "w"), indent=1)
+    print(open(f"profiles/{out_tag}_summary.md").read())
 
 
 if __name__ == "__main__":
