@@ -288,3 +288,29 @@ def test_host_frames_close_and_rows_all_equal_the_per_clip_accessors(model_path)
     pinned = torch.empty(n * pipe.tracker.rows_cap * 64, dtype=torch.uint8).pin_memory()
     counts2, rows2 = pipe.rows_all(out=pinned)
     assert np.array_equal(counts2, counts) and all(np.array_equal(rows2[c, :counts[c]], rows[c, :counts[c]]) for c in range(n))
+
+
+def test_more_than_64_clips_step_in_chunks_of_kernel_argument_metadata(model_path):
+    """The tracker step carries frame times / clip ids in its kernel arguments, 64 slots per launch: 130 clips take three
+    launches per step and must behave like 130 independent single-clip pipelines (checked on a sample of clips)."""
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    n, T = 130, 5
+    bg = [synth.background(500 + (c % 7)) for c in range(n)]
+    frames = np.stack([np.stack([synth.render(bg[c], 3 * (c % 11) + t) for c in range(n)]) for t in range(T)])
+    st = torch.cuda.current_stream().cuda_stream
+    pipe = Pipeline(model_path, n, max_frames=T, fps=np.where(np.arange(n) % 2 == 0, 30.0, 60.0), detection_treshold=0.3, rows_per_frame=25)
+    fd = torch.from_numpy(frames).to("cuda:0")
+    for t in range(T):
+        pipe.step(fd[t], st)
+    best, rows_n, nph, ovf, ph = pipe.close(cap=8)
+    counts, rows = pipe.rows_all()
+    assert np.all(ovf == 0) and int(counts.sum()) > 100
+    for c in (0, 63, 64, 65, 127, 128, 129):
+        one = Pipeline(model_path, 1, max_frames=T, fps=30.0 if c % 2 == 0 else 60.0, detection_treshold=0.3, rows_per_frame=25)
+        for t in range(T):
+            one.step(fd[t, c:c + 1].contiguous(), st)
+        one.close()
+        c1, r1 = one.rows_all()
+        assert c1[0] == counts[c] and np.array_equal(r1[0, :c1[0]], rows[c, :counts[c]]), c

@@ -1,8 +1,4 @@
 cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 300 --warmup 10 --cpu-frames 0 --no-extras --no-roofline"
-for c in 2 3; do
-VBT_AUTOTUNE_CONCURRENCY=$c VBT_PLAN_FILE=/tmp/plan_c$c $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('autotune concurrency $c:', round(d['value']), round(d['ms_per_step'],4))"
-VBT_PLAN_FILE=/tmp/plan_c$c $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('  rerun same plan:', round(d['value']), round(d['ms_per_step'],4))"
-cp /tmp/plan_c$c.b64.f0 gpurun_out/plan_c$c.b64.f0
-done
-VBT_PLAN_FILE=$PWD/profiles/plan_lite0 $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pinned plan:', round(d['value']), round(d['ms_per_step'],4))"
+export VBT_PLAN_FILE=$PWD/profiles/plan_lite0
+python tools/step_times.py 64 2>/dev/null | grep -E "expand_dw|total" | cut -c1-112
+python bench.py --steps 300 --warmup 10 --cpu-frames 0 --no-extras --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('depth3', round(d['value']), round(d['ms_per_step'],4))"

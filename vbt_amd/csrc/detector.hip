@@ -1595,7 +1595,7 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
   a.PH = std::max((a.OH - 1) * dop.stride + dop.k, a.pad_t + a.H);
   a.PW = std::max((a.OW - 1) * dop.stride + dop.k, a.pad_l + a.W);
   const int KS64 = (tin.c + 63) / 64, K = tin.c, Ce = te.c, nch = (Ce + 63) / 64, kk = dop.k * dop.k, KT = (kk + 3) / 4;
-  a.T0S = KS64 * 64 + 16;
+  a.T0S = KS64 * 64 + 32;   // 160 / 224-byte rows: the expand's 16-byte B-operand reads (16 pixels x 4 k-groups) are bank-conflict-free (144 / 208 are 2-way)
   a.nchunks = nch;
   a.cpw = 1;
   const int8_t* we = (const int8_t*)(m->blob.data() + eop.w_off);

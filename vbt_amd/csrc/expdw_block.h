@@ -29,7 +29,7 @@ struct ExpDwArgs {
   int H, W, Cin, OH, OW, Ce;
   int PW, PH;        // bordered E image
   int pad_t, pad_l;
-  int T0S;           // KS64 * 64 + 16
+  int T0S;           // KS64 * 64 + 32
   int nchunks, cpw;  // 64-channel chunks in all / per workgroup
   const v4i* we;     // expand weights [chunk][ks][t][lane] x 16 B: row i of tile t = channel 64c + 16t + i, k = 64ks + 16g + j
   const int* be;     // bias with the input zero point folded, padded to 64 * nchunks
