@@ -23,9 +23,10 @@ def oracle_run(oracle_lib, model_path, frames):
 
 # plan flags (include/vbt_hip.h): 1 = one kernel per graph op; 8 = no autotuning -> the most fused alternative of
 # every group (incl. whole BiFPN nodes; low-resolution MBConv blocks as whole-image expand+depthwise + projection GEMM
-# with the residual in its epilogue); 8|4096 = the same with those blocks on the tile kernel; 8|2 = dw+project fused,
+# with the residual in its epilogue; BiFPN nodes and head layers on row bands); 8|4096 / 8|8192 = the same with those
+# blocks / layers on the 64-pixel tile kernel; 8|128 = one launch per head layer and level; 8|2 = dw+project fused,
 # expand separate; 8|16 = no BiFPN node fusion; 0 = autotuned mix (whatever is fastest on this GPU)
-@pytest.mark.parametrize("flags", [1, 8, 8 | 4096, 8 | 2, 8 | 16, 8 | 128, 8 | 256, 8 | 512 | 4096, 8 | 1024, 8 | 2048 | 4096, 0])
+@pytest.mark.parametrize("flags", [1, 8, 8 | 4096 | 8192, 8 | 8192, 8 | 2, 8 | 16, 8 | 128 | 8192, 8 | 128, 8 | 256, 8 | 512 | 4096, 8 | 1024, 8 | 2048 | 4096, 0])
 def test_every_tensor_bit_exact(model_path, frames, oracle_run, flags):
     """Every plan must reproduce the oracle bit for bit: all 250 tensors when unfused, every tensor that still
     reaches HBM otherwise (fused MBConv / SeparableConv blocks keep their intermediates in LDS)."""
@@ -94,7 +95,7 @@ def test_explicit_clamps_bit_exact(tmp_path, model_path, oracle_lib, frames):
     path = str(tmp_path / "clamped.vbtm")
     open(path, "wb").write(bytes(raw))
     det = oracle_lib.OracleDetector(path)
-    for flags in (1, 8, 8 | 4096, 0):
+    for flags in (1, 8, 8 | 4096 | 8192, 0):
         it = Interpreter(path, max_batch=2, flags=flags)
         boxes, scores, classes, counts = it.detect(frames[:2])
         for b in range(2):
@@ -144,7 +145,7 @@ def tie_model(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("flags", [1, 8, 8 | 4096, 8 | 2, 8 | 16, 8 | 512 | 4096, 8 | 1024, 0])
+@pytest.mark.parametrize("flags", [1, 8, 8 | 4096 | 8192, 8 | 2, 8 | 16, 8 | 512 | 4096, 8 | 1024, 0])
 def test_integer_add_ties_bit_exact_in_every_fused_path(tie_model, oracle_lib, frames, flags):
     """add_kernel, the residual epilogues (tile and whole-image MBConv), the node load stage (2-input and chained 3-input
     sums) and the node chain all evaluate the same integer ADD: every tensor equals the oracle on the tie model."""

@@ -1,0 +1,166 @@
+// SeparableConv (depthwise 3x3 / 1 SAME -> pointwise) on ROW BANDS of a 64-channel map: the BiFPN nodes and the box / class
+// head layers of EfficientDet-Lite0 (BiFPN width 64).  Optional BiFPN node input: the band is the sum (+ReLU6) of two or
+// three resampled sources (binary integer ADDs, node_sum4 of fused_block.h).
+//
+// Why not the 64-pixel tile kernel (fused_block.h) here: on these layers a tile does ~120 wave-instructions of
+// requantisation but ~550 in all - tile decode, halo addressing, parameter loads, the epilogue's addressing are paid per 64
+// pixels, and every tile re-reads a 1-pixel halo.  A band is `rows` full-width rows of one image (up to 320 pixels): the
+// per-workgroup costs are paid once per band, the halo is two rows, the projection weights / biases are staged in LDS
+// once, and the projection is dealt in (pixel group, 16-channel tile) units, so a 9- or 36-channel head output costs a
+// quarter / three quarters of a 64-channel one instead of the same.
+// LDS:  T0 [(rows+2)*(W+2)][80]  input band with its 1-pixel border (zero point outside the image)
+//       D  [rows*W (16-padded)][80]  depthwise output
+//       WP [4][64] x 16 B  projection weights, natural channel order | bias int[64] | mult float[64]
+// 16 wavefronts; both stages on the 16x16x64 int8 MFMA (depthwise as a diagonal-embedded matrix product, four taps per
+// instruction: three instructions for 3x3).  Arithmetic identical to the per-op kernels.
+#pragma once
+
+constexpr int BD_WAVES = 16, BD_THREADS = 64 * BD_WAVES;
+constexpr int BD_ST = 80;   // bytes per pixel row of T0 and D
+
+struct BandArgs {
+  const int8_t* x;   // [B][H][W][64] (plain input; unused when n_src > 0)
+  int8_t* out;       // [B][H][W][Cout]
+  int H, W, Cout, rows, nbands;
+  unsigned zx4;      // zero point of the depthwise input x4
+  const v4i* wd;     // [cg][m][lane] x 16 B: row i = channel 16cg + i, k = 16g + j -> tap 4m + g, diagonal j == i
+  const int* bd;     // bias with the input zero point folded (64)
+  const float* md;
+  Rq rqd;
+  const v4i* wp;     // [t][lane] x 16 B: row i = output channel 16t + i, k = 16g + j (K = 64: one MFMA step)
+  const int* bp;     // bias with the depthwise output's zero point folded, padded to 64
+  const float* mp;
+  Rq rqp;
+  // BiFPN node: see FusedArgs
+  int n_src, chain;
+  const int8_t* src[3];
+  int sh[3], sw[3], smode[3], spt[3], spl[3];
+  AddQ sumq, preq;
+};
+
+__device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long b, int iy, int ix, int cd, bool up2) {
+  const int8_t* sb = a.src[j] + b * (long)a.sh[j] * a.sw[j] * 64 + 4 * cd;
+  if (a.smode[j] == 0) return *(const unsigned*)(sb + (iy * a.sw[j] + ix) * 64);
+  if (a.smode[j] == 1) {
+    int yy, xx;
+    if (up2) { yy = iy >> 1; xx = ix >> 1; }
+    else { yy = (iy * a.sh[j]) / a.H; xx = (ix * a.sw[j]) / a.W; }
+    return *(const unsigned*)(sb + (yy * a.sw[j] + xx) * 64);
+  }
+  unsigned lo = 0u, hi = 0u;   // 3x3/2 max pool read in place on the u8 image of the bytes (out-of-map taps = -128)
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++) {
+    const int yy = iy * 2 + ky - a.spt[j], yc = min(max(yy, 0), a.sh[j] - 1);
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      const int xx = ix * 2 + kx - a.spl[j], xc = min(max(xx, 0), a.sw[j] - 1);
+      unsigned t = *(const unsigned*)(sb + (yc * a.sw[j] + xc) * 64);
+      t = (yy == yc && xx == xc) ? (t ^ 0x80808080u) : 0u;
+      lo = pk_max_u16(lo, t & 0x00FF00FFu);
+      hi = pk_max_u16(hi, (t >> 8) & 0x00FF00FFu);
+    }
+  }
+  return (lo | (hi << 8)) ^ 0x80808080u;
+}
+
+__global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem[];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 12; i++)
+    if (i < mt.n && (int)blockIdx.x >= mt.start[i]) pi = i;
+  const BandArgs& a = probs[pi];
+  const int local = (int)blockIdx.x - mt.start[pi];
+  const long b = local / a.nbands;
+  const int band = local - (int)b * a.nbands;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int y0 = band * a.rows, nr = min(a.rows, a.H - y0);
+  const int PW = a.W + 2, NPh = (nr + 2) * PW, NPo = nr * a.W, NPG = (NPo + 15) >> 4;
+  unsigned char* T0 = bd_smem;
+  unsigned char* D = T0 + (a.rows + 2) * PW * BD_ST;
+  unsigned char* WP = D + (((a.rows * a.W + 15) >> 4) << 4) * BD_ST;   // 4 KB weights | 256 B bias | 256 B mult
+  const int NT = (a.Cout + 15) >> 4;
+
+  // ---- stage L: band + border -> T0; projection weights / bias / multipliers -> LDS ----
+  for (int i = tid; i < NT * 64; i += BD_THREADS) *(v4i*)(WP + 16 * i) = a.wp[i];
+  if (tid < 16) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.bp + 16 * tid);
+  else if (tid < 32) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.mp + 16 * (tid - 16));
+  const float rcp_pw = 1.0f / (float)PW;
+  if (a.n_src > 0) {
+    const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
+    for (int i = tid; i < NPh * 16; i += BD_THREADS) {   // 4 channels per lane-iteration
+      const int p = i >> 4, cd = i & 15;
+      const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
+      const int iy = y0 + hy - 1, ix = hx - 1;
+      unsigned v = a.zx4;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        unsigned us[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          if (j < a.n_src) us[j] = band_source4(a, j, b, iy, ix, cd, up2[j]);
+        if (a.chain == 0) v = addq4(us[0], us[1], a.sumq);
+        else {
+          const unsigned pp = addq4(us[0], us[1], a.preq);
+          v = a.chain == 1 ? addq4(pp, us[2], a.sumq) : addq4(us[2], pp, a.sumq);
+        }
+      }
+      *(unsigned*)(T0 + p * BD_ST + 4 * cd) = v;
+    }
+  } else {
+    const int8_t* xb = a.x + b * (long)a.H * a.W * 64;
+    const uint4 z4 = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
+    for (int i = tid; i < NPh * 4; i += BD_THREADS) {    // 16 bytes per lane-iteration
+      const int p = i >> 2, sg = i & 3;
+      const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
+      const int iy = y0 + hy - 1, ix = hx - 1;
+      uint4 v = z4;
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xb + (iy * a.W + ix) * 64 + 16 * sg);
+      *(uint4*)(T0 + p * BD_ST + 16 * sg) = v;
+    }
+  }
+  // depthwise operands of this wave's channel group (requested before the barrier)
+  const int cg = wave & 3;
+  v4i wdv[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++) wdv[m] = a.wd[(cg * 3 + m) * 64 + lane];
+  const int4 bq = *(const int4*)(a.bd + 16 * cg + 4 * g);
+  const float4 mu = *(const float4*)(a.md + 16 * cg + 4 * g);
+  int tapoff[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    const int tap = min(4 * m + g, 8);
+    tapoff[m] = ((tap / 3) * PW + (tap % 3)) * BD_ST;
+  }
+  const float rcp_w = 1.0f / (float)a.W;
+  __syncthreads();
+  // ---- stage D: depthwise; unit = (output pixel group, channel group cg) ----
+  for (int pg = wave >> 2; pg < NPG; pg += BD_WAVES / 4) {
+    const int slot = pg * 16 + r, sc = min(slot, NPo - 1);
+    const int py = fdiv_small(sc, rcp_w), px = sc - py * a.W;
+    const unsigned char* pb = T0 + (py * PW + px) * BD_ST + 16 * cg;
+    v4i acc = v4i_from(bq);
+#pragma unroll
+    for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wdv[m], *(const v4i*)(pb + tapoff[m]), acc, 0, 0, 0);
+    *(unsigned*)(D + slot * BD_ST + 16 * cg + 4 * g) = rq_pack_b(acc, mu, a.rqd);
+  }
+  __syncthreads();
+  // ---- stage P: projection; unit = (pixel group, 16-channel output tile) ----
+  const int NU = NPG * NT;
+  for (int u = wave; u < NU; u += BD_WAVES) {
+    const int pg = u / NT, t = u - pg * NT;
+    const int slot = pg * 16 + r;
+    const int c0 = 16 * t + 4 * g;
+    const v4i wv = *(const v4i*)(WP + (t * 64 + lane) * 16);
+    const v4i bv = *(const v4i*)(D + slot * BD_ST + 16 * g);
+    v4i acc = v4i_from(*(const int4*)(WP + 4096 + 4 * c0));
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, bv, acc, 0, 0, 0);
+    const unsigned d = rq_pack_b(acc, *(const float4*)(WP + 4096 + 256 + 4 * c0), a.rqp);
+    if (slot < NPo && c0 < a.Cout) {
+      int8_t* o = a.out + ((b * a.H + y0) * (long)a.W + slot) * a.Cout + c0;   // the band's pixels are contiguous: (y0 + py) * W + px = y0 * W + slot
+      if ((a.Cout & 3) == 0) *(unsigned*)o = d;
+      else
+        for (int j = 0; j < 4; j++)
+          if (c0 + j < a.Cout) o[j] = (int8_t)(d >> (8 * j));
+    }
+  }
+}

@@ -167,6 +167,7 @@ __device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_
 #include "image_block.h"
 #include "node_chain.h"
 #include "expdw_block.h"
+#include "band_block.h"
 
 // ------------------------------------------------------------------------------------------
 // pointwise conv on the gfx950 double-rate int8 MFMA (v_mfma_i32_16x16x64_i8: same 16 issue cycles as the legacy
@@ -961,10 +962,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_CHAIN, F_EXPDW, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_CHAIN, F_EXPDW, F_BAND, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
                                            "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node", "fused_heads_multi",
-                                           "fused_stem_block", "fused_bifpn_chain", "fused_expand_dw"};
+                                           "fused_stem_block", "fused_bifpn_chain", "fused_expand_dw", "fused_sepconv_band"};
 
 struct Step {
   int op;       // index into ops
@@ -996,6 +997,10 @@ struct Step {
   FusedArgs* d_multi = nullptr;
   // F_STEMBLK: stem -> depthwise -> project in one kernel (op = project op, e_op = stem op)
   StemBlockArgs sb;
+  // F_BAND: SeparableConv / BiFPN node on row bands (band_block.h); members non-empty: several problems in one grid
+  BandArgs bd_args;
+  BandArgs* d_band = nullptr;   // device copy of the problem list (pointers are those of the whole batch)
+  int band_tiles = 0;           // workgroups per image of this problem
   // F_EXPDW: expand + depthwise on whole images, expanded channels split over workgroups (expdw_block.h; op = depthwise op)
   ExpDwArgs xd;
   // F_MBCONV on a low-resolution map: per-chunk weight records of the whole-image kernel (data == nullptr: not built)
@@ -1366,6 +1371,116 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   return VBT_OK;
 }
 
+// the alternative of a group that runs it as ONE tile-kernel launch (fused_block.h), or nullptr
+static const Alt* tile_alt(const Group& g, int family) {
+  for (int i = (int)g.alts.size() - 1; i >= 0; i--)
+    if (g.alts[i].steps.size() == 1 && g.alts[i].steps[0].family == family) return &g.alts[i];
+  return nullptr;
+}
+static const Alt* band_alt(const Group& g) {
+  for (int i = (int)g.alts.size() - 1; i >= 0; i--)
+    if (g.alts[i].steps.size() == 1 && g.alts[i].steps[0].family == F_BAND && g.alts[i].steps[0].members.empty()) return &g.alts[i];
+  return nullptr;
+}
+
+// ---- SeparableConv / BiFPN node on row bands (band_block.h) ----
+static bool band_ok(const vbt_model* m, int d_op, int p_op) {
+  if (m->flags & VBT_MODEL_NO_BAND) return false;
+  if (const char* ns = getenv("VBT_SUBSTREAMS")) if (atoi(ns) > 1) return false;   // the problem list holds whole-batch pointers
+  const OpRec& d = m->ops[d_op];
+  const OpRec& p = m->ops[p_op];
+  const TensorRec& ti = m->tensors[d.inputs[0]];
+  const TensorRec& to = m->tensors[p.output];
+  return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && ti.c == 64 && to.c <= 64 && to.h == ti.h && to.w == ti.w && ti.w <= 160;
+}
+static int band_lds(const BandArgs& a) {
+  return (a.rows + 2) * (a.W + 2) * BD_ST + (((a.rows * a.W + 15) >> 4) << 4) * BD_ST + 4096 + 512;
+}
+static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc* ns, Step* out) {
+  const OpRec& dop = m->ops[d_op];
+  const OpRec& pop = m->ops[p_op];
+  const TensorRec& tin = m->tensors[dop.inputs[0]];
+  const TensorRec& td = m->tensors[dop.output];
+  const TensorRec& to = m->tensors[pop.output];
+  Step s;
+  s.family = F_BAND;
+  s.op = p_op;
+  s.d_op = d_op;
+  s.p_op = p_op;
+  s.sum_op = sum_op;
+  BandArgs& a = s.bd_args;
+  memset(&a, 0, sizeof(a));
+  a.H = tin.h; a.W = tin.w; a.Cout = to.c;
+  const int nb = std::max(1, (tin.h * tin.w + 319) / 320);
+  a.rows = (tin.h + nb - 1) / nb;
+  a.nbands = (tin.h + a.rows - 1) / a.rows;
+  a.zx4 = (unsigned)(tin.zero_point & 255) * 0x01010101u;
+  const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
+  const int32_t* bqd = (const int32_t*)(m->blob.data() + dop.b_off);
+  const float* mud = (const float*)(m->blob.data() + dop.m_off);
+  const int8_t* wpj = (const int8_t*)(m->blob.data() + pop.w_off);
+  std::vector<v4i> pd((size_t)4 * 3 * 64, (v4i){0, 0, 0, 0}), pp((size_t)4 * 64, (v4i){0, 0, 0, 0});
+  int8_t* od = (int8_t*)pd.data();
+  for (int cg = 0; cg < 4; cg++)
+    for (int mi = 0; mi < 3; mi++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int i = lane & 15, g = lane >> 4, ch = 16 * cg + i, tap = 4 * mi + g;
+        for (int j = 0; j < 16; j++) od[(((size_t)(cg * 3 + mi) * 64 + lane) * 16) + j] = (tap < 9 && j == i) ? wd[(size_t)tap * 64 + ch] : 0;
+      }
+  int8_t* op_ = (int8_t*)pp.data();
+  for (int t = 0; t < 4; t++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int i = lane & 15, g = lane >> 4, co = 16 * t + i;
+      for (int j = 0; j < 16; j++) op_[(((size_t)t * 64 + lane) * 16) + j] = co < to.c ? wpj[(size_t)co * 64 + 16 * g + j] : 0;
+    }
+  std::vector<int> bd(64, 0);
+  std::vector<float> md(mud, mud + 64);
+  for (int ch = 0; ch < 64; ch++) {
+    long sw = 0;
+    for (int t = 0; t < 9; t++) sw += wd[(size_t)t * 64 + ch];
+    bd[ch] = (int)((long)bqd[ch] - (long)tin.zero_point * sw);
+  }
+  v4i *dpd, *dpp;
+  int* dbd;
+  float* dmd;
+  int rc;
+  if ((rc = upload(m, pd, &dpd)) || (rc = upload(m, pp, &dpp)) || (rc = upload(m, bd, &dbd)) || (rc = upload(m, md, &dmd))) return rc;
+  a.wd = dpd; a.wp = dpp; a.bd = dbd; a.md = dmd;
+  a.bp = m->op_steps[p_op].bias;   // folded with the depthwise output's zero point, padded to 64
+  a.mp = m->op_steps[p_op].mult;
+  a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max);
+  a.rqp = make_rq(to.zero_point, pop.act_min, pop.act_max);
+  a.x = m->tptr[dop.inputs[0]];
+  a.out = m->tptr[pop.output];
+  std::vector<int> parts{d_op, p_op, sum_op};
+  if (sum_op >= 0) {
+    a.n_src = ns->n;
+    a.x = nullptr;
+    for (int j = 0; j < ns->n; j++) {
+      const TensorRec& ts = m->tensors[ns->tensor[j]];
+      a.src[j] = m->tptr[ns->tensor[j]];
+      a.sh[j] = ts.h; a.sw[j] = ts.w; a.smode[j] = ns->mode[j];
+      if (ns->mode[j] == 2) { a.spt[j] = m->ops[ns->rs_op[j]].pad_t; a.spl[j] = m->ops[ns->rs_op[j]].pad_l; }
+      parts.push_back(ns->rs_op[j]);
+    }
+    a.sumq = m->op_steps[sum_op].addq;
+    a.chain = 0;
+    if (ns->pre_add >= 0) { a.chain = ns->chain; a.preq = m->op_steps[ns->pre_add].addq; parts.push_back(ns->pre_add); }
+  }
+  s.band_tiles = a.nbands;
+  s.lds_bytes = band_lds(a);
+  std::vector<BandArgs> one{a};
+  if ((rc = upload(m, one, &s.d_band))) return rc;
+  for (int oi : parts)
+    if (oi >= 0) {
+      s.alg_bytes_per_frame += m->op_steps[oi].alg_bytes_per_frame;
+      s.weight_bytes += m->op_steps[oi].weight_bytes;
+      s.macs_per_frame += m->op_steps[oi].macs_per_frame;
+    }
+  *out = s;
+  return VBT_OK;
+}
+
 // The box / class heads run the same SeparableConv chain on 5 pyramid levels (x 2 heads): layer j of every
 // chain is independent of layer j of the others, so all of them go out as ONE grid (fused_block_multi_kernel).
 static int batch_heads(vbt_model* m) {
@@ -1375,9 +1490,9 @@ static int batch_heads(vbt_model* m) {
   int nchains = 0, first = -1;
   for (int gi = 0; gi < (int)m->groups.size(); gi++) {
     const Group& g = m->groups[gi];
-    const Alt& fa = g.alts.back();
-    if (fa.steps.size() != 1 || fa.steps[0].family != F_SEPCONV) continue;
-    const Step& st = fa.steps[0];
+    const Alt* fap = tile_alt(g, F_SEPCONV);
+    if (!fap) continue;
+    const Step& st = fap->steps[0];
     if (m->ops[st.d_op].level < 0) continue;
     int tin = m->ops[st.d_op].inputs[0], tout = m->ops[st.p_op].output;
     auto it = by_tensor.find(tin);
@@ -1400,10 +1515,10 @@ static int batch_heads(vbt_model* m) {
   };
   auto mergeable = [&](const std::vector<int>& mem) {
     if (mem.size() < 2 || mem.size() > 12) return false;
-    const Step& s0 = m->groups[mem[0]].alts.back().steps[0];
+    const Step& s0 = tile_alt(m->groups[mem[0]], F_SEPCONV)->steps[0];
     if (!((s0.nbp == 1 || s0.nbp == 2) && m->ops[s0.d_op].k == 3 && m->ops[s0.d_op].stride == 1)) return false;  // the instantiations built below
     for (int gi : mem) {
-      const Step& st = m->groups[gi].alts.back().steps[0];
+      const Step& st = tile_alt(m->groups[gi], F_SEPCONV)->steps[0];
       if (st.nbp != s0.nbp || m->ops[st.d_op].k != 3 || m->ops[st.d_op].stride != 1) return false;
     }
     return true;
@@ -1415,10 +1530,15 @@ static int batch_heads(vbt_model* m) {
   std::vector<char> consumed(m->groups.size(), 0);
   for (int d = d0; d <= maxd; d++) {
     std::vector<int> mem = members_of(d);
-    const Step& s0 = m->groups[mem[0]].alts.back().steps[0];
+    const Step& s0 = tile_alt(m->groups[mem[0]], F_SEPCONV)->steps[0];
     Group g;
-    Alt unf, each, multi;
-    Step ms;
+    Alt unf, each, multi, bandm;
+    Step ms, bs;
+    bs.family = F_BAND;
+    bs.op = s0.op;
+    bs.d_op = s0.d_op;
+    std::vector<BandArgs> bargs;
+    bool all_band = true;
     ms.family = F_MULTI;
     ms.op = s0.op;
     ms.d_op = s0.d_op;
@@ -1428,9 +1548,21 @@ static int batch_heads(vbt_model* m) {
     for (int gi : mem) {
       const Group& src = m->groups[gi];
       for (const Step& st : src.alts[0].steps) unf.steps.push_back(st);
-      const Step& fs = src.alts.back().steps[0];
+      const Alt* ta = tile_alt(src, F_SEPCONV);
+      const Step& fs = ta->steps[0];
       each.steps.push_back(fs);
-      for (int t : src.alts.back().hidden) { each.hidden.push_back(t); multi.hidden.push_back(t); }
+      for (int t : ta->hidden) { each.hidden.push_back(t); multi.hidden.push_back(t); bandm.hidden.push_back(t); }
+      if (const Alt* ba = band_alt(src)) {
+        const Step& b1 = ba->steps[0];
+        bs.members.push_back(b1);
+        bargs.push_back(b1.bd_args);
+        bs.lds_bytes = std::max(bs.lds_bytes, b1.lds_bytes);
+        bs.alg_bytes_per_frame += b1.alg_bytes_per_frame;
+        bs.weight_bytes += b1.weight_bytes;
+        bs.macs_per_frame += b1.macs_per_frame;
+      } else {
+        all_band = false;
+      }
       ms.members.push_back(fs);
       ms.lds_bytes = std::max(ms.lds_bytes, fs.lds_bytes);
       ms.alg_bytes_per_frame += fs.alg_bytes_per_frame;
@@ -1450,6 +1582,13 @@ static int batch_heads(vbt_model* m) {
     g.alts.push_back(each);
     g.alts.push_back(multi);
     g.chosen = 2;
+    if (all_band && bargs.size() <= 12) {   // the same layer of every chain on row bands, one grid
+      int rcb = upload(m, bargs, &bs.d_band);
+      if (rcb) return rcb;
+      bandm.steps.push_back(bs);
+      g.alts.push_back(bandm);
+      g.chosen = 3;
+    }
     at[last] = g;
   }
   std::vector<Group> out;
@@ -1764,6 +1903,17 @@ static int fuse_plan(vbt_model* m) {
         a2.hidden.push_back(op.output);
         a2.hidden.push_back(m->ops[i + 1].output);
         g.alts.push_back(a2);
+        if (band_ok(m, i + 1, i + 2) && m->tensors[op.output].c == 64) {   // the same node on row bands (band_block.h)
+          Alt a3;
+          Step s3;
+          rc = make_band(m, i + 1, i + 2, i, &ns, &s3);
+          if (rc) return rc;
+          if (s3.lds_bytes <= 160 * 1024) {
+            a3.steps.push_back(s3);
+            a3.hidden = a2.hidden;
+            g.alts.push_back(a3);
+          }
+        }
       }
       g.chosen = (int)g.alts.size() - 1;
       m->groups.push_back(g);
@@ -1878,6 +2028,17 @@ static int fuse_plan(vbt_model* m) {
         a2.steps.push_back(s);
         a2.hidden.push_back(op.output);
         g.alts.push_back(a2);
+        if (band_ok(m, i, i + 1)) {
+          Alt a3;
+          Step s3;
+          rc = make_band(m, i, i + 1, -1, nullptr, &s3);
+          if (rc) return rc;
+          if (s3.lds_bytes <= 160 * 1024) {
+            a3.steps.push_back(s3);
+            a3.hidden.push_back(op.output);
+            g.alts.push_back(a3);
+          }
+        }
       }
     } else {
       Alt unf;
@@ -1901,9 +2062,9 @@ static int fuse_plan(vbt_model* m) {
 static int chain_nodes(vbt_model* m) {
   if (!(m->flags & VBT_MODEL_NODE_CHAIN)) return VBT_OK;  // opt-in: measured slower than one launch per node at B = 64
   auto small_node = [&](const Group& g) {
-    const Alt& fa = g.alts.back();
-    if (fa.steps.size() != 1 || fa.steps[0].family != F_NODE) return false;
-    const Step& st = fa.steps[0];
+    const Alt* fap = tile_alt(g, F_NODE);
+    if (!fap) return false;
+    const Step& st = fap->steps[0];
     const OpRec& d = m->ops[st.d_op];
     const int HW = st.fa.H * st.fa.W, NB = (st.fa.Cout + 63) / 64;
     return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= 400 &&
@@ -1949,7 +2110,7 @@ static int chain_nodes(vbt_model* m) {
       cs.family = F_CHAIN;
       std::vector<FusedArgs> hargs;
       for (size_t ci : chain) {
-        const Alt& fa = m->groups[ci].alts.back();
+        const Alt& fa = *tile_alt(m->groups[ci], F_NODE);
         const Step& ns = fa.steps[0];
         each.steps.push_back(ns);
         for (int t : fa.hidden) { each.hidden.push_back(t); ch.hidden.push_back(t); }
@@ -2462,6 +2623,30 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         attr_set = true;
       }
       node_chain_kernel<<<dim3((unsigned)B), NC_THREADS, s.lds_bytes, st>>>(s.d_multi, (int)s.members.size());
+      break;
+    }
+    case F_BAND: {
+      if (boff != 0) { set_error("fused_sepconv_band: sub-batch streams are not supported (VBT_SUBSTREAMS)"); return VBT_ERR_ARG; }
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+      }
+      MultiTiles mt;
+      int acc = 0;
+      if (s.members.empty()) {
+        mt.n = 1;
+        mt.start[0] = 0;
+        acc = B * s.band_tiles;
+      } else {
+        mt.n = (int)s.members.size();
+        for (int i = 0; i < mt.n; i++) {
+          mt.start[i] = acc;
+          acc += B * s.members[i].band_tiles;
+        }
+      }
+      mt.start[mt.n] = acc;
+      sepconv_band_kernel<<<dim3((unsigned)acc), BD_THREADS, s.lds_bytes, st>>>(s.d_band, mt);
       break;
     }
     case F_EXPDW: {
