@@ -59,6 +59,7 @@ int vbt_model_create(const char* container_path, int device, int max_batch, vbt_
 #define VBT_MODEL_NODE_CHAIN 1024     /* experimental: runs of small BiFPN nodes as ONE launch, one workgroup per image (node_chain.h) */
 #define VBT_MODEL_CHUNK48 2048        /* heuristic plan: 48-channel chunks in fused MBConv blocks whose expanded width allows it */
 #define VBT_MODEL_IMAGE_BLOCKS 512    /* heuristic plan: whole-image MBConv kernel wherever it applies (autotuning decides otherwise) */
+#define VBT_MODEL_TILE128 16384       /* heuristic plan: 128-pixel tiles in the fused MBConv blocks that allow them */
 #define VBT_MODEL_NO_BAND 8192        /* do not use the row-band SeparableConv kernel of the BiFPN nodes / head layers */
 #define VBT_MODEL_NO_EXPDW 4096       /* do not use the whole-image expand+depthwise kernel of the low-resolution MBConv blocks */
 #define VBT_MODEL_NO_AUTOTUNE 8     /* keep the heuristic plan (most fused alternative, default kernel variants) */

@@ -17,7 +17,7 @@ import json
 import shutil
 import sys
 
-FAM = (("expdw_image", "fused_expand_dw"), ("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"),
+FAM = (("expdw_image", "fused_expand_dw"), ("sepconv_band", "fused_sepconv_band"), ("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"),
        ("mbconv_image", "fused_mbconv"), ("dw_tile", "dw_conv"), ("dw_col", "dw_conv"), ("dw_kernel", "dw_conv"),
        ("pw_a", "pw_conv_mfma_i8"), ("pw_b", "pw_conv_mfma_i8"), ("pw_c", "pw_conv_mfma_i8"), ("stem_kernel", "stem_conv_mfma_i8"),
        ("add_kernel", "add_requant"), ("maxpool", "maxpool3x3s2"), ("resize_kernel", "resize_nn"), ("postprocess", "decode_nms"),
@@ -144,7 +144,7 @@ def main():
         f.write(f"\nVALU issue floor of the forward: {valu/1e6:.0f} M wave-instructions x 2..4 cycles / 1024 SIMDs / 2.4 GHz = "
                 f"{valu*2/SIMDS/CLOCK*1e3:.3f}..{valu*4/SIMDS/CLOCK*1e3:.3f} ms (two or more waves per SIMD issue every 2 cycles, one wave every 4).\n\n")
         # the two fractions BASELINE.json's north_star names
-        dw_fams = [k for k in fams if k in ("dw_conv", "fused_expand_dw")]
+        dw_fams = [k for k in fams if k in ("dw_conv", "fused_expand_dw", "fused_sepconv_band")]
         pw = "pw_conv_mfma_i8"
         f.write("## The two counter-derived fractions named by the north_star\n\n")
         nstar = {}

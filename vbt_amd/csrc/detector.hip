@@ -1135,16 +1135,16 @@ static void pack_weights64(const int8_t* w, int N, int K, int KS, int NB, std::v
 }
 
 // ---- fusion pass: MBConv (pw+relu6 -> dw -> pw [-> add]) and SeparableConv (dw -> pw) -> fused_block_kernel ----
-static void choose_tile(int OH, int OW, int KK, int S, bool expand, int* TXo, int* TYo) {
+static void choose_tile(int OH, int OW, int KK, int S, bool expand, int* TXo, int* TYo, int slots = 64) {
   double best = 1e300;
   for (int TX = 1; TX <= std::min(OW, 64); TX++) {
     int TXp = (TX + 3) & ~3;
-    int TY = std::min(OH, 64 / TXp);
+    int TY = std::min(OH, slots / TXp);
     if (TY < 1) continue;
     int tiles = ((OW + TX - 1) / TX) * ((OH + TY - 1) / TY);
     int NPh = ((TXp - 1) * S + KK) * ((TY - 1) * S + KK);
     // halo pixels cost expand work + LDS loads; every tile also pays the 64-slot depthwise/project work
-    double cost = tiles * ((expand ? 1.0 : 0.35) * NPh + 64.0);
+    double cost = tiles * ((expand ? 1.0 : 0.35) * NPh + (double)slots);
     if (cost < best) { best = cost; *TXo = TX; *TYo = TY; }
   }
 }
@@ -2324,6 +2324,15 @@ static void launch_pw_a(int MS, dim3 grid, hipStream_t st, const int8_t* x, cons
   else pw_a_kernel<KS, 1><<<grid, 256, 0, st>>>(x, wp, e, ra, out, M, K, N, NB, nb_per_y);
 }
 
+static bool ppw2_fits(const vbt_model* m, const Step& st) {
+  const OpRec& dop = m->ops[st.d_op];
+  int TX, TY;
+  choose_tile(st.fa.OH, st.fa.OW, dop.k, dop.stride, true, &TX, &TY, 128);
+  const int TXp = (TX + 3) & ~3;
+  const int NPh = ((TXp - 1) * dop.stride + dop.k) * ((TY - 1) * dop.stride + dop.k);
+  return ((NPh * st.fa.T0S + 15) & ~15) + ((NPh * FB_EST + 15) & ~15) + 128 * FB_DST <= 64 * 1024;
+}
+
 // Launches one plan step for frames [boff, boff + B) of the batch (every tensor is batch-major).
 // Whole-image MBConv kernel (image_block.h): eligibility and launch geometry.
 struct ImageGeom { int PW, PH, NB, maxu, lds; bool ok; };
@@ -2542,7 +2551,8 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const bool ex = s.family == F_MBCONV;
       // (the tile option of the variant is applied below, before the launch macros use `grid` / `lds_bytes`)
       // variant bit 0: depthwise on the matrix pipe (default) / VALU; bits 1..: 0 = heuristic tile, 1 = half-height tile
-      const int var = s.variant < 0 ? (((m->flags & VBT_MODEL_IMAGE_BLOCKS) && image_geom(m, s).ok) ? 5 : ((m->flags & VBT_MODEL_CHUNK48) ? 9 : 1)) : s.variant;
+      int var = s.variant < 0 ? (((m->flags & VBT_MODEL_IMAGE_BLOCKS) && image_geom(m, s).ok) ? 5 : ((m->flags & VBT_MODEL_CHUNK48) ? 9 : 1)) : s.variant;
+      if (s.variant < 0 && (m->flags & VBT_MODEL_TILE128) && s.family == F_MBCONV && s.nbp <= 2 && (a.KSe == 1 || a.KSe == 2) && ppw2_fits(m, s)) var |= 16;
       const bool mdw = var & 1;
       const bool nt3 = (var & 8) && mdw && a.nch3 > 0 && s.nbp <= 2 && a.KSe >= 1 && a.KSe <= 4;  // 48-channel chunks
       if (var & 4) {  // one workgroup per image (low-resolution blocks)
@@ -2575,6 +2585,37 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         const int TXp_ = (a.TX + 3) & ~3;
         const int NPh_ = ((TXp_ - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
         lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * 72 + 15) & ~15) + 64 * FB_DST;
+      }
+      // variant bit 4: 128-pixel tiles (PPW = 2), matrix-pipe depthwise, register-resident expand weights (K <= 64), <= 128 output channels
+      const bool ppw2 = (var & 16) && ex && mdw && (a.KSe == 1 || a.KSe == 2) && s.nbp <= 2 && !((var >> 1) & 1);
+      if (ppw2) {
+        choose_tile(a.OH, a.OW, dop.k, dop.stride, true, &a.TX, &a.TY, 128);
+        a.tiles_x = (a.OW + a.TX - 1) / a.TX;
+        a.tiles_y = (a.OH + a.TY - 1) / a.TY;
+        const int TXp_ = (a.TX + 3) & ~3;
+        const int NPh_ = ((TXp_ - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
+        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * (nt3 ? 72 : FB_EST) + 15) & ~15) + 128 * FB_DST;
+        grid = dim3((unsigned)((long)B * a.tiles_x * a.tiles_y));
+#define FB_P2(KK, S, NBP, KSE)                                                                                      \
+  do {                                                                                                              \
+    if (nt3) fused_block_kernel<KK, S, NBP, true, true, KSE, 3, 2><<<grid, 256, lds_bytes, st>>>(a);                \
+    else fused_block_kernel<KK, S, NBP, true, true, KSE, 4, 2><<<grid, 256, lds_bytes, st>>>(a);                    \
+  } while (0)
+#define FB_P2K(KK, S)                                                                                               \
+  do {                                                                                                              \
+    if (s.nbp == 1 && a.KSe == 1) FB_P2(KK, S, 1, 1);                                                               \
+    else if (s.nbp == 1) FB_P2(KK, S, 1, 2);                                                                        \
+    else if (a.KSe == 1) FB_P2(KK, S, 2, 1);                                                                        \
+    else FB_P2(KK, S, 2, 2);                                                                                        \
+  } while (0)
+        if (lds_bytes > 64 * 1024) { set_error("fused_mbconv: 128-pixel tile needs %d bytes of LDS", lds_bytes); return VBT_ERR_ARG; }
+        if (dop.k == 3 && dop.stride == 1) FB_P2K(3, 1);
+        else if (dop.k == 3 && dop.stride == 2) FB_P2K(3, 2);
+        else if (dop.k == 5 && dop.stride == 1) FB_P2K(5, 1);
+        else FB_P2K(5, 2);
+#undef FB_P2K
+#undef FB_P2
+        break;
       }
 #define FB_LAUNCH(KK, S, NBP)                                                                              \
   do {                                                                                                     \
@@ -2778,6 +2819,10 @@ static void autotune(vbt_model* m) {
           cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
           if (image_geom(m, st).ok) cand.push_back(5);  // one workgroup per image
           if (st.family == F_MBCONV && st.fa.nch3 > 0 && st.nbp <= 2 && st.fa.KSe >= 1 && st.fa.KSe <= 4) { cand.push_back(9); cand.push_back(11); }  // 48-channel chunks
+          if (st.family == F_MBCONV && st.nbp <= 2 && (st.fa.KSe == 1 || st.fa.KSe == 2) && ppw2_fits(m, st)) {   // 128-pixel tiles
+            cand.push_back(17);
+            if (st.fa.nch3 > 0) cand.push_back(25);
+          }
         } else if (st.family == F_MULTI) {
           cand = {0, 1};
         } else if (st.family == F_EXPDW) {
