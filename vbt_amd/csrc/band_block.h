@@ -71,7 +71,7 @@ __global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs
     if (i < mt.n && (int)blockIdx.x >= mt.start[i]) pi = i;
   const BandArgs& a = probs[pi];
   const int local = (int)blockIdx.x - mt.start[pi];
-  const long b = local / a.nbands;
+  const long b = fdiv_small(local, frcp(a.nbands));
   const int band = local - (int)b * a.nbands;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int y0 = band * a.rows, nr = min(a.rows, a.H - y0);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs
   for (int i = tid; i < NT * 64; i += BD_THREADS) *(v4i*)(WP + 16 * i) = a.wp[i];
   if (tid < 16) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.bp + 16 * tid);
   else if (tid < 32) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.mp + 16 * (tid - 16));
-  const float rcp_pw = 1.0f / (float)PW;
+  const float rcp_pw = frcp(PW);
   if (a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
     for (int i = tid; i < NPh * 16; i += BD_THREADS) {   // 4 channels per lane-iteration
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs
     const int tap = min(4 * m + g, 8);
     tapoff[m] = ((tap / 3) * PW + (tap % 3)) * BD_ST;
   }
-  const float rcp_w = 1.0f / (float)a.W;
+  const float rcp_w = frcp(a.W);
   __syncthreads();
   // ---- stage D: depthwise; unit = (output pixel group, channel group cg) ----
   for (int pg = wave >> 2; pg < NPG; pg += BD_WAVES / 4) {
@@ -146,8 +146,9 @@ __global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs
   __syncthreads();
   // ---- stage P: projection; unit = (pixel group, 16-channel output tile) ----
   const int NU = NPG * NT;
+  const float rcp_nt = frcp(NT);
   for (int u = wave; u < NU; u += BD_WAVES) {
-    const int pg = u / NT, t = u - pg * NT;
+    const int pg = fdiv_small(u, rcp_nt), t = u - pg * NT;
     const int slot = pg * 16 + r;
     const int c0 = 16 * t + 4 * g;
     const v4i wv = *(const v4i*)(WP + (t * 64 + lane) * 16);

@@ -100,6 +100,9 @@ __device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, 
 }
 // exact n / d for 0 <= n < 2^20, 1 <= d <= 4096 without the ~40-instruction integer division
 __device__ __forceinline__ int fdiv_small(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
+// reciprocal for fdiv_small: one v_rcp_f32 (1 ulp) instead of the IEEE division sequence.  (n + 0.5) / d lies at least
+// 0.5 / d away from an integer and the product carries < 2^-22 relative error, so the floor is exact for n < 2^20.
+__device__ __forceinline__ float frcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
 __device__ __forceinline__ v4i v4i_from(const int4& b) { return (v4i){b.x, b.y, b.z, b.w}; }
 
 __device__ __forceinline__ unsigned rq_pack_i(const v4i& acc, const int4& b, const float4& mu, const Rq& q) {

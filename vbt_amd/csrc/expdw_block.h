@@ -47,23 +47,24 @@ __global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xd_smem[];
   constexpr int KT = (KK * KK + 3) / 4;   // depthwise MFMAs per unit: four taps each
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
-  const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
-  const long b = blockIdx.x / ngroups;
+  const int ngroups = fdiv_small(a.nchunks + a.cpw - 1, frcp(a.cpw));
+  const long b = fdiv_small((int)blockIdx.x, frcp(ngroups));
   const int grp = blockIdx.x - (int)b * ngroups;
   const int HW = a.H * a.W, OHW = a.OH * a.OW;
   const int NPGi = (HW + 15) >> 4, NPGo = (OHW + 15) >> 4;
   unsigned char* T0 = xd_smem;
   unsigned char* E = T0 + ((HW * a.T0S + 15) & ~15);
   unsigned char* D = E + a.PH * a.PW * XD_EST;
-  const float rcp_w = 1.0f / (float)a.W, rcp_ow = 1.0f / (float)a.OW;
+  const float rcp_w = frcp(a.W), rcp_ow = frcp(a.OW);
 
   // ---- input image -> T0 (16-byte granules; Cin % 16 == 0), E <- zero point everywhere (the border keeps it) ----
   {
     const int ng = a.Cin >> 4;
+    const float rcp_ng = frcp(ng);
     const int8_t* xb = a.x + b * (long)HW * a.Cin;
     for (int i = tid; i < HW * ng; i += XD_THREADS) {
-      const int p = i / ng, sg = i - p * ng;
-      *(uint4*)(T0 + p * a.T0S + 16 * sg) = *(const uint4*)(xb + (long)p * a.Cin + 16 * sg);
+      const int p = fdiv_small(i, rcp_ng), sg = i - p * ng;
+      *(uint4*)(T0 + p * a.T0S + 16 * sg) = *(const uint4*)(xb + p * a.Cin + 16 * sg);
     }
     const uint4 z4 = make_uint4(a.zeb, a.zeb, a.zeb, a.zeb);
     for (int i = tid; i < a.PH * a.PW * (XD_EST / 16); i += XD_THREADS) *(uint4*)(E + 16 * i) = z4;
@@ -135,10 +136,11 @@ __global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
     // ---- stage O: D -> the depthwise output tensor, 16 bytes per lane, only the chunk's real channels ----
     {
       const int nv = min(64, a.Ce - 64 * c) >> 4;   // 16-byte parts of this chunk (Ce % 16 == 0)
+      const float rcp_nv = frcp(nv);
       int8_t* ob = a.out + b * (long)OHW * a.Ce + 64 * c;
       for (int i = tid; i < OHW * nv; i += XD_THREADS) {
-        const int slot = i / nv, part = i - slot * nv;
-        *(uint4*)(ob + (long)slot * a.Ce + 16 * part) = *(const uint4*)(D + slot * XD_EST + 16 * part);
+        const int slot = fdiv_small(i, rcp_nv), part = i - slot * nv;
+        *(uint4*)(ob + slot * a.Ce + 16 * part) = *(const uint4*)(D + slot * XD_EST + 16 * part);
       }
     }
   }

@@ -98,15 +98,18 @@ template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4
 __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, unsigned char* fb_smem) {
   static_assert(PPW == 1 || MDW, "128-pixel tiles exist for the matrix-pipe depthwise only");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
-  const int tx = tile % a.tiles_x;
-  tile /= a.tiles_x;
-  const int ty = tile % a.tiles_y;
-  const long b = tile / a.tiles_y;
+  // tile -> (image, ty, tx) and every later pixel -> (row, column) split go through fdiv_small: no integer division
+  // (~40 VALU instructions each) anywhere in the prologue
+  const int trow = fdiv_small(tile, frcp(a.tiles_x));
+  const int tx = tile - trow * a.tiles_x;
+  const int bimg = fdiv_small(trow, frcp(a.tiles_y));
+  const int ty = trow - bimg * a.tiles_y;
+  const long b = bimg;
   const int oy0 = ty * a.TY, ox0 = tx * a.TX;
   const int TXp = (a.TX + 3) & ~3;
   const int HWx = (TXp - 1) * S + KK, HWy = (a.TY - 1) * S + KK, NPh = HWx * HWy;
   const int iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
-  const float rcp_hwx = 1.0f / (float)HWx, rcp_txp = 1.0f / (float)TXp;
+  const float rcp_hwx = frcp(HWx), rcp_txp = frcp(TXp);
   unsigned char* T0 = fb_smem;
   unsigned char* E = T0 + ((NPh * a.T0S + 15) & ~15);
   // 48-channel chunks keep E rows at 72 bytes: fewer bank conflicts in the depthwise reads (18-dword pixel stride: conflict-
@@ -128,15 +131,13 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
     // BiFPN node input: resample + binary integer ADD(s) + clamp, 4 channels per lane-iteration (same arithmetic as add_kernel)
     const int nd = a.Cin >> 2;
     const unsigned zb4 = (unsigned)(a.zx & 255) * 0x01010101u;
-    const int pstep = 256 / nd;                       // pixels advanced per round (planner guarantees nd <= 256)
-    int p = tid / nd;
+    const int pstep = fdiv_small(256, frcp(nd));      // pixels advanced per round (planner guarantees nd <= 256)
+    int p = fdiv_small(tid, frcp(nd));
     const int cd = tid - p * nd;
-    int hy = p / HWx, hx = p - hy * HWx;
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
     for (; tid < pstep * nd && p < NPh; p += pstep) {
+      const int hy = fdiv_small(p, rcp_hwx), hx = p - hy * HWx;
       const int iy = iy0 + hy, ix = ix0 + hx;
-      hx += pstep;
-      while (hx >= HWx) { hx -= HWx; hy++; }
       unsigned v = zb4;
       if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
         unsigned us[3] = {0u, 0u, 0u};
@@ -193,33 +194,29 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       const unsigned zb1 = (unsigned)(a.zx & 255) * 0x01010101u;
       const uint4 zb = make_uint4(zb1, zb1, zb1, zb1);
       const int8_t* xb = a.x + b * (long)a.H * a.W * a.Cin;
-      const int pstep = 256 / ng;
-      int p = tid / ng;
+      const int pstep = fdiv_small(256, frcp(ng));
+      int p = fdiv_small(tid, frcp(ng));
       const int sg = tid - p * ng;
-      int hy = p / HWx, hx = p - hy * HWx;
       for (; tid < pstep * ng && p < NPh; p += pstep) {
+        const int hy = fdiv_small(p, rcp_hwx), hx = p - hy * HWx;
         const int iy = iy0 + hy, ix = ix0 + hx;
         uint4 v = zb;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xb + ((long)iy * a.W + ix) * a.Cin + 16 * sg);
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xb + (iy * a.W + ix) * a.Cin + 16 * sg);
         *(uint4*)(T0 + p * a.T0S + 16 * sg) = v;
-        hx += pstep;
-        while (hx >= HWx) { hx -= HWx; hy++; }
       }
     } else {
     const int ng = a.Cin >> 3;
     const unsigned long long zb = (unsigned long long)(a.zx & 255) * 0x0101010101010101ull;
     const int8_t* xb = a.x + b * (long)a.H * a.W * a.Cin;
-    const int pstep = 256 / ng;
-    int p = tid / ng;
+    const int pstep = fdiv_small(256, frcp(ng));
+    int p = fdiv_small(tid, frcp(ng));
     const int sg = tid - p * ng;
-    int hy = p / HWx, hx = p - hy * HWx;
     for (; tid < pstep * ng && p < NPh; p += pstep) {
+      const int hy = fdiv_small(p, rcp_hwx), hx = p - hy * HWx;
       const int iy = iy0 + hy, ix = ix0 + hx;
       unsigned long long v = zb;
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const unsigned long long*)(xb + ((long)iy * a.W + ix) * a.Cin + 8 * sg);
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const unsigned long long*)(xb + (iy * a.W + ix) * a.Cin + 8 * sg);
       *(unsigned long long*)(T0 + p * a.T0S + 8 * sg) = v;
-      hx += pstep;
-      while (hx >= HWx) { hx -= HWx; hy++; }
     }
     }
   }
@@ -256,7 +253,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   // depthwise lane geometry
   const int cq = tid & 15, strip = tid >> 4;
   const int nsx = TXp >> 2;
-  const int sy = strip / nsx, sx = (strip - sy * nsx) * 4;
+  const int sy = fdiv_small(strip, frcp(nsx)), sx = (strip - sy * nsx) * 4;
   const bool dw_active = sy < a.TY;
   // MDW: lane (r = pixel of a 16-slot group, g) -> halo offset of the slot's window origin, per slot group
   int hbase[4 * PPW];

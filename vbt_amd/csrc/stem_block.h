@@ -52,11 +52,12 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
   unsigned char* const P = PD;
   unsigned char* const D = PD;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
-  int tile = blockIdx.x;
-  const int tx = tile % a.tiles_x;
-  tile /= a.tiles_x;
-  const int ty = tile % a.tiles_y;
-  const long b = tile / a.tiles_y;
+  const int tile = blockIdx.x;
+  const int trow = fdiv_small(tile, frcp(a.tiles_x));
+  const int tx = tile - trow * a.tiles_x;
+  const int bimg = fdiv_small(trow, frcp(a.tiles_y));
+  const int ty = trow - bimg * a.tiles_y;
+  const long b = bimg;
   const int oy0 = ty * 16, ox0 = tx * 16;
   const int sy0 = oy0 - 1, sx0 = ox0 - 1;                      // depthwise 3x3/1 SAME: one halo pixel
   const int iy0 = 2 * sy0 - a.spad_t, ix0 = 2 * sx0 - a.spad_l;

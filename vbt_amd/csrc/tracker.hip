@@ -980,6 +980,10 @@ int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* prm,
   if (hipMalloc((void**)&t->nph, sizeof(int) * n_clips) != hipSuccess) return fail("nph");
   if (hipMalloc((void**)&t->T, sizeof(int) * n_clips) != hipSuccess) return fail("T");
   if (hipMalloc((void**)&t->best, sizeof(int) * n_clips) != hipSuccess) return fail("best");
+  // the clip-close record buffers (device + pinned host) at their largest size: no allocation on the first close
+  t->summary_bytes = (16 + (size_t)MAXPH * 48) * n_clips;
+  if (hipMalloc((void**)&t->d_summary, t->summary_bytes) != hipSuccess) return fail("summary");
+  if (hipHostMalloc((void**)&t->h_summary, t->summary_bytes, hipHostMallocDefault) != hipSuccess) return fail("pinned summary");
   init_states_kernel<<<(n_clips + 63) / 64, 64>>>(t->states, n_clips);
   VBT_HIP_CHECK(hipDeviceSynchronize());
   *out = t;
