@@ -1236,6 +1236,25 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     long* dwdm; int* dbm;
     if ((rc = upload(m, wdm, &dwdm)) || (rc = upload(m, biasm, &dbm))) return rc;
     a.wdm = dwdm; a.bdm = dbm;
+    if (expand && (dop.k == 3 || dop.k == 5)) {   // 16x16x64 form (FusedArgs::wd64)
+      const int K64 = dop.k == 3 ? 3 : 7, k = dop.k;
+      std::vector<v4i> w64((size_t)(Cp / 16) * K64 * 64, (v4i){0, 0, 0, 0});
+      int8_t* o = (int8_t*)w64.data();
+      for (int q = 0; q < Cp / 16; q++)
+        for (int mi = 0; mi < K64; mi++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int i = lane & 15, g = lane >> 4, c = 16 * q + i;
+            int tap = -1;
+            if (k == 3) tap = g < 3 ? mi * 3 + g : -1;
+            else if (mi < 5) tap = mi * 5 + g;
+            else if (mi == 5) tap = g * 5 + 4;
+            else tap = g == 0 ? 24 : -1;
+            if (tap >= 0 && c < Ce) o[(((size_t)q * K64 + mi) * 64 + lane) * 16 + i] = w[(size_t)tap * Ce + c];
+          }
+      v4i* d64;
+      if ((rc = upload(m, w64, &d64))) return rc;
+      a.wd64 = d64;
+    }
     a.zd = tdout.zero_point; a.lod = dop.act_min; a.hid = dop.act_max;
     a.rqd = make_rq(a.zd, a.lod, a.hid);
   }
@@ -2329,9 +2348,9 @@ static void launch_pw_a(int MS, dim3 grid, hipStream_t st, const int8_t* x, cons
 
 static bool ppw2_fits(const vbt_model* m, const Step& st) {
   const OpRec& dop = m->ops[st.d_op];
-  int TX, TY;
-  choose_tile(st.fa.OH, st.fa.OW, dop.k, dop.stride, true, &TX, &TY, 128);
-  const int TXp = (TX + 3) & ~3;
+  const int TX = 16, TY = 8;   // the 128-pixel kernels are DW64 (fused_block.h): 16 x 8 tiles only
+  if (st.fa.OW < TX || st.fa.OH < TY || !st.fa.wd64) return false;
+  const int TXp = TX;
   const int NPh = ((TXp - 1) * dop.stride + dop.k) * ((TY - 1) * dop.stride + dop.k);
   return ((NPh * st.fa.T0S + 15) & ~15) + ((NPh * FB_EST + 15) & ~15) + 128 * FB_DST <= 64 * 1024;
 }
@@ -2592,17 +2611,18 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       // variant bit 4: 128-pixel tiles (PPW = 2), matrix-pipe depthwise, register-resident expand weights (K <= 64), <= 128 output channels
       const bool ppw2 = (var & 16) && ex && mdw && (a.KSe == 1 || a.KSe == 2) && s.nbp <= 2 && !((var >> 1) & 1);
       if (ppw2) {
-        choose_tile(a.OH, a.OW, dop.k, dop.stride, true, &a.TX, &a.TY, 128);
+        a.TX = 16; a.TY = 8;
         a.tiles_x = (a.OW + a.TX - 1) / a.TX;
         a.tiles_y = (a.OH + a.TY - 1) / a.TY;
         const int TXp_ = (a.TX + 3) & ~3;
         const int NPh_ = ((TXp_ - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
-        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * (nt3 ? 72 : FB_EST) + 15) & ~15) + 128 * FB_DST;
+        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * FB_EST + 15) & ~15) + 128 * FB_DST;
         grid = dim3((unsigned)((long)B * a.tiles_x * a.tiles_y));
+        if (a.OW < 16 || a.OH < 8 || !a.wd64) { set_error("fused_mbconv: the 128-pixel variant needs maps of at least 16 x 8"); return VBT_ERR_ARG; }
 #define FB_P2(KK, S, NBP, KSE)                                                                                      \
   do {                                                                                                              \
-    if (nt3) fused_block_kernel<KK, S, NBP, true, true, KSE, 3, 2><<<grid, 256, lds_bytes, st>>>(a);                \
-    else fused_block_kernel<KK, S, NBP, true, true, KSE, 4, 2><<<grid, 256, lds_bytes, st>>>(a);                    \
+    if (nt3) fused_block_kernel<KK, S, NBP, true, true, KSE, 3, 2, true><<<grid, 256, lds_bytes, st>>>(a);          \
+    else fused_block_kernel<KK, S, NBP, true, true, KSE, 4, 2, true><<<grid, 256, lds_bytes, st>>>(a);              \
   } while (0)
 #define FB_P2K(KK, S)                                                                                               \
   do {                                                                                                              \
@@ -2620,9 +2640,23 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
 #undef FB_P2
         break;
       }
+      // 64-pixel tiles of exactly 8 x 8 outputs, K <= 64, <= 128 output channels: depthwise on the 16x16x64 MFMA (DW64)
+      const bool dw64 = ex && mdw && a.wd64 && a.TX == 8 && a.TY == 8 && (a.KSe == 1 || a.KSe == 2) && s.nbp <= 2 && !getenv("VBT_NO_DW64");
+      if (dw64 && nt3) {   // E rows are 80 bytes in the DW64 kernels
+        const int NPh_ = ((8 - 1) * dop.stride + dop.k) * ((8 - 1) * dop.stride + dop.k);
+        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * FB_EST + 15) & ~15) + 64 * FB_DST;
+      }
+#define FB_DW64(KK, S, NBP)                                                                                \
+  do {                                                                                                     \
+    if (nt3 && a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 3, 1, true><<<grid, 256, lds_bytes, st>>>(a);      \
+    else if (nt3) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 2, 3, 1, true><<<grid, 256, lds_bytes, st>>>(a);              \
+    else if (a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 4, 1, true><<<grid, 256, lds_bytes, st>>>(a);       \
+    else fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 2, 4, 1, true><<<grid, 256, lds_bytes, st>>>(a);                       \
+  } while (0)
 #define FB_LAUNCH(KK, S, NBP)                                                                              \
   do {                                                                                                     \
-    if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 3><<<grid, 256, lds_bytes, st>>>(a);      \
+    if (dw64) FB_DW64(KK, S, NBP);                                                                          \
+    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 3><<<grid, 256, lds_bytes, st>>>(a);      \
     else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 2) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 2, 3><<<grid, 256, lds_bytes, st>>>(a); \
     else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 3) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 3, 3><<<grid, 256, lds_bytes, st>>>(a); \
     else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 4) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 4, 3><<<grid, 256, lds_bytes, st>>>(a); \
@@ -2650,6 +2684,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       else FB_NBP(5, 2);
 #undef FB_NBP
 #undef FB_LAUNCH
+#undef FB_DW64
       break;
     }
     case F_CHAIN: {

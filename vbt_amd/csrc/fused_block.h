@@ -47,6 +47,12 @@ struct FusedArgs {
   // folded for raw int8 inputs (bias - z_x * sum(w))
   const long* wdm;
   const int* bdm;
+  // the same for the 16x16x64 MFMA (DW64): [16-channel group q][m][lane] x 16 B, lane (i = lane & 15 -> channel 16q + i,
+  // g = lane >> 4): byte j is non-zero only for j == i and holds the weight of tap (m, g):
+  //   3x3: (row m, column g), g = 3 is a zero column           -> 3 instructions
+  //   5x5: m < 5: (row m, column g); m = 5: (row g, column 4); m = 6: g = 0 -> (4, 4), the rest zero -> 7 instructions
+  // so the B operand of (m, g) sits at a compile-time offset from one of two per-lane base addresses
+  const v4i* wd64;
   // project
   const long* wp;   // packed, K = Ce_pad
   const int* bp;
@@ -94,9 +100,14 @@ constexpr int FB_DST = 72;  // D tile bytes per pixel
 // PPW: 16-pixel output slot groups per wave.  2 -> 128-pixel tiles (matrix-pipe depthwise only): the per-tile prologue /
 // epilogue addressing is paid once per 128 pixels, the halo shrinks (3x3: 1.41x instead of 1.56x, 5x5: 1.88x / 2.25x)
 // and 12 halo pixel groups split evenly over the 4 waves of the expand stage.
-template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4, int PPW = 1>
+// DW64: depthwise on the 16x16x64 MFMA, four taps per instruction, for tiles of exactly (8 * PPW) x 8 output pixels: the halo
+// row length is then a compile-time constant and every LDS address of the stage is `lane base + immediate` - no address
+// arithmetic in the stage at all (the 16x16x32 form spends one v_add per ds_read_b64 and needs 5 / 13 instructions per
+// pixel group instead of 3 / 7).
+template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4, int PPW = 1, bool DW64 = false>
 __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, unsigned char* fb_smem) {
   static_assert(PPW == 1 || MDW, "128-pixel tiles exist for the matrix-pipe depthwise only");
+  static_assert(!DW64 || (EXPAND && MDW && (KK == 3 || KK == 5)), "DW64: fused expand blocks, 3x3 / 5x5");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   // tile -> (image, ty, tx) and every later pixel -> (row, column) split go through fdiv_small: no integer division
   // (~40 VALU instructions each) anywhere in the prologue
@@ -114,7 +125,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   unsigned char* E = T0 + ((NPh * a.T0S + 15) & ~15);
   // 48-channel chunks keep E rows at 72 bytes: fewer bank conflicts in the depthwise reads (18-dword pixel stride: conflict-
   // free at stride 1, 2-way at stride 2; 80 bytes gives 2-way / 4-way) and less LDS per workgroup
-  constexpr int EST = (EXPAND && NT == 3) ? 72 : FB_EST;
+  constexpr int EST = (EXPAND && NT == 3 && !DW64) ? 72 : FB_EST;   // DW64 reads 16-byte groups: rows stay 16-byte aligned
   unsigned char* D = E + (EXPAND ? ((NPh * EST + 15) & ~15) : 0);
   // SeparableConv / node / head tiles whose depthwise input is ONE 64-channel chunk (BiFPN width 64): the projection
   // weights and its bias / multipliers are copied into LDS while the input tile loads, so the projection and the epilogue
@@ -259,7 +270,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   int hbase[4 * PPW];
 #pragma unroll
   for (int pg = 0; pg < 4 * PPW; pg++) hbase[pg] = 0;
-  if constexpr (MDW) {
+  if constexpr (MDW && !DW64) {
 #pragma unroll
     for (int pg = 0; pg < 4 * PPW; pg++) {
       int slot = pg * 16 + r;
@@ -366,7 +377,37 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       __syncthreads();
     }
     // ---- stage D: depthwise on chunk c ----
-    if constexpr (MDW) {
+    if constexpr (DW64) {
+      constexpr int TXP = 8 * PPW, HWX = (TXP - 1) * S + KK;
+      constexpr int KT64 = KK == 3 ? 3 : 7;
+      constexpr int PGS = (16 / TXP) * S * HWX * FB_EST;   // slot group pg -> pg + 1
+      if (NT == 4 || wave < NT) {   // wave = 16-channel group of the chunk (48-channel chunks: wave 3 sits this stage out)
+        const v4i* wm = a.wd64 + ((long)(c * NT + wave) * KT64) * 64 + lane;
+        v4i wreg[KT64];
+#pragma unroll
+        for (int mi = 0; mi < KT64; mi++) wreg[mi] = wm[mi * 64];
+        const int4 bqm = *(const int4*)(a.bdm + c * CH + 16 * wave + 4 * g);
+        const float4 mum = *(const float4*)(a.md + c * CH + 16 * wave + 4 * g);
+        const int hb = TXP == 8 ? ((r >> 3) * S * HWX + (r & 7) * S) : r * S;   // window origin of slot r of group 0
+        const unsigned char* baseH = E + hb * FB_EST + 16 * wave + g * FB_EST;          // g = column of the tap
+        const unsigned char* baseV = E + hb * FB_EST + 16 * wave + g * (HWX * FB_EST);  // g = row of the tap (5x5, column 4)
+#pragma unroll
+        for (int pg = 0; pg < 4 * PPW; pg += 2) {   // two slot groups at a time: independent accumulate chains
+          v4i dqa = v4i_from(bqm), dqb = v4i_from(bqm);
+#pragma unroll
+          for (int mi = 0; mi < KT64; mi++) {
+            const unsigned char* bp = (KK == 5 && mi == 5) ? baseV : baseH;
+            const int off = KK == 3 ? mi * HWX * FB_EST : (mi < 5 ? mi * HWX * FB_EST : (mi == 5 ? 4 * FB_EST : (4 * HWX + 4) * FB_EST));
+            const v4i bva = *(const v4i*)(bp + pg * PGS + off);
+            const v4i bvb = *(const v4i*)(bp + (pg + 1) * PGS + off);
+            dqa = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], bva, dqa, 0, 0, 0);
+            dqb = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], bvb, dqb, 0, 0, 0);
+          }
+          *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dqa, mum, a.rqd);
+          *(unsigned*)(D + ((pg + 1) * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dqb, mum, a.rqd);
+        }
+      }
+    } else if constexpr (MDW) {
       // Matrix-pipe depthwise: out[c][p] = sum_t W'[c][(t,c')] * X[(t,c')][p] with W' = w[t][c] * delta(c,c').
       // One 16x16x32 MFMA covers 2 taps x 16 channels; wave w owns channel group w of the chunk, the B operand
       // (8 consecutive channels of pixel p + tap) is a single ds_read_b64 from the NHWC tile.  Exact int32.
@@ -539,10 +580,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
 #ifndef FB_MINW
 #define FB_MINW 1
 #endif
-template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4, int PPW = 1>
+template <int KK, int S, int NBP, bool EXPAND, bool MDW, int KSE = 0, int NT = 4, int PPW = 1, bool DW64 = false>
 __global__ __launch_bounds__(256, FB_MINW) void fused_block_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem_dyn[];
-  fused_block_body<KK, S, NBP, EXPAND, MDW, KSE, NT, PPW>(a, blockIdx.x, fb_smem_dyn);
+  fused_block_body<KK, S, NBP, EXPAND, MDW, KSE, NT, PPW, DW64>(a, blockIdx.x, fb_smem_dyn);
 }
 
 // Several independent problems (e.g. the same head layer on all 5 pyramid levels of both heads) in ONE grid:
