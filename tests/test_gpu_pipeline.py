@@ -314,3 +314,31 @@ def test_more_than_64_clips_step_in_chunks_of_kernel_argument_metadata(model_pat
         one.close()
         c1, r1 = one.rows_all()
         assert c1[0] == counts[c] and np.array_equal(r1[0, :c1[0]], rows[c, :counts[c]]), c
+
+
+@pytest.mark.parametrize("depth", [1, 3, 4])
+def test_tracker_on_the_detector_streams_gives_the_same_rows(model_path, monkeypatch, depth):
+    """VBT_TRACKER_STREAM=inline (the OC-SORT step at the end of the slot's own stream, ordered by events) against the
+    tracker stream of the default configuration: identical DataFrame rows and phases at every depth."""
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    n, T = 5, 20
+    frames = np.stack([np.stack([synth.render(synth.background(70 + c), 7 * c + t) for c in range(n)]) for t in range(T)])
+    fd = torch.from_numpy(frames).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for mode in ("own", "inline"):
+        monkeypatch.setenv("VBT_TRACKER_STREAM", mode)
+        pipe = Pipeline(model_path, n, max_frames=T, fps=60.0, depth=depth)
+        assert pipe._trk_inline == (mode == "inline")
+        for t in range(T):
+            pipe.step(fd[t], st)
+        best, n_rows, nph, ovf, ph = pipe.close(cap=16)
+        counts, rows = pipe.rows_all()
+        out[mode] = (best.copy(), n_rows.copy(), nph.copy(), ph.copy(), counts.copy(), [rows[c][:counts[c]].tobytes() for c in range(n)])
+    a, b = out["own"], out["inline"]
+    for i in range(5):
+        assert np.array_equal(a[i], b[i])
+    assert int(a[1].sum()) > 10
+    assert a[5] == b[5]
