@@ -147,21 +147,34 @@ __global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs
   // ---- stage P: projection; unit = (pixel group, 16-channel output tile) ----
   const int NU = NPG * NT;
   const float rcp_nt = frcp(NT);
-  for (int u = wave; u < NU; u += BD_WAVES) {
-    const int pg = fdiv_small(u, rcp_nt), t = u - pg * NT;
+  auto project_unit = [&](int pg, int t, const v4i& wv, const int4& bb, const float4& mm) {
     const int slot = pg * 16 + r;
     const int c0 = 16 * t + 4 * g;
-    const v4i wv = *(const v4i*)(WP + (t * 64 + lane) * 16);
     const v4i bv = *(const v4i*)(D + slot * BD_ST + 16 * g);
-    v4i acc = v4i_from(*(const int4*)(WP + 4096 + 4 * c0));
+    v4i acc = v4i_from(bb);
     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, bv, acc, 0, 0, 0);
-    const unsigned d = rq_pack_b(acc, *(const float4*)(WP + 4096 + 256 + 4 * c0), a.rqp);
+    const unsigned d = rq_pack_b(acc, mm, a.rqp);
     if (slot < NPo && c0 < a.Cout) {
       int8_t* o = a.out + ((b * a.H + y0) * (long)a.W + slot) * a.Cout + c0;   // the band's pixels are contiguous: (y0 + py) * W + px = y0 * W + slot
       if ((a.Cout & 3) == 0) *(unsigned*)o = d;
       else
         for (int j = 0; j < 4; j++)
           if (c0 + j < a.Cout) o[j] = (int8_t)(d >> (8 * j));
+    }
+  };
+  if (NT == 4) {
+    // 64 output channels (every layer but the heads' last): unit u = wave + 16 i is tile t = wave & 3 of pixel group
+    // (wave >> 2) + 4 i, so the wave's weights / bias / multipliers are loop invariants
+    const int t = wave & 3, c0 = 16 * t + 4 * g;
+    const v4i wv = *(const v4i*)(WP + (t * 64 + lane) * 16);
+    const int4 bb = *(const int4*)(WP + 4096 + 4 * c0);
+    const float4 mm = *(const float4*)(WP + 4096 + 256 + 4 * c0);
+    for (int pg = wave >> 2; pg < NPG; pg += BD_WAVES / 4) project_unit(pg, t, wv, bb, mm);
+  } else {
+    for (int u = wave; u < NU; u += BD_WAVES) {
+      const int pg = fdiv_small(u, rcp_nt), t = u - pg * NT;
+      const int c0 = 16 * t + 4 * g;
+      project_unit(pg, t, *(const v4i*)(WP + (t * 64 + lane) * 16), *(const int4*)(WP + 4096 + 4 * c0), *(const float4*)(WP + 4096 + 256 + 4 * c0));
     }
   }
 }

@@ -1690,8 +1690,22 @@ static int make_stem_block(vbt_model* m, int si, Step* out) {
     if ((rc = upload(m, ws, &dws)) || (rc = upload(m, bs, &dbs)) || (rc = upload(m, ms, &dms))) return rc;
     a.ws = dws; a.bs = dbs; a.ms = dms;
   }
-  const Step& ds = m->op_steps[si + 1];  // matrix-pipe depthwise weights of the dw op
-  a.wdm = ds.wdm; a.bdm = ds.bdm; a.mdm = ds.mdm;
+  const Step& ds = m->op_steps[si + 1];  // matrix-pipe depthwise bias / multipliers of the dw op
+  a.bdm = ds.bdm; a.mdm = ds.mdm;
+  {  // depthwise weights in the 16x16x64 form: [cg][m][lane] x 16 B, tap (row m, column g), diagonal byte i
+    const int8_t* w = (const int8_t*)(m->blob.data() + d.w_off);
+    std::vector<v4i> w64(2 * 3 * 64, (v4i){0, 0, 0, 0});
+    int8_t* o = (int8_t*)w64.data();
+    for (int cg = 0; cg < 2; cg++)
+      for (int mi = 0; mi < 3; mi++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int i = lane & 15, g = lane >> 4;
+          if (g < 3) o[(((size_t)cg * 3 + mi) * 64 + lane) * 16 + i] = w[(size_t)(mi * 3 + g) * 32 + 16 * cg + i];
+        }
+    v4i* d64;
+    if ((rc = upload(m, w64, &d64))) return rc;
+    a.wd64 = d64;
+  }
   {  // project: row i = cout i, K = 32
     const int8_t* w = (const int8_t*)(m->blob.data() + p.w_off);
     const int32_t* bq = (const int32_t*)(m->blob.data() + p.b_off);

@@ -7,11 +7,12 @@
 //   R  [37][120]    raw uint8 rows of the patch (dword-aligned start, out-of-image dwords = input zero point)
 //   P  [336][32]    per stem pixel of the 18x18 halo: kernel row 0|1|2 as 8 bytes each (px0 RGB px1 RGB px2 RG)
 //                   + the three px2-B bytes: exactly the K=32 operand of one 16x16x32 int8 MFMA
-//   S  [324][40]    stem output on the halo, int8 x 32 channels (out-of-map pixels = its zero point: the
-//                   depthwise pads ITS input)
+//   S  [324][48]    stem output on the halo, int8 x 32 channels (out-of-map pixels = its zero point: the
+//                   depthwise pads ITS input); 48-byte rows: 16-byte aligned channel groups, conflict-free b128 reads
 //   D  [256][40]    depthwise output, int8 x 32 channels
 // stem / project: weights are the MFMA A operand so a lane ends with consecutive output channels of one pixel;
-// depthwise: diagonal-embedded weights on the matrix pipe (see fused_block.h).
+// depthwise: diagonal-embedded weights on the 16x16x64 MFMA, tap (row m, column g) per instruction m and lane group g
+// (three instructions for 3x3, every LDS address = lane base + immediate; see DW64 in fused_block.h).
 #pragma once
 
 struct StemBlockArgs {
@@ -26,7 +27,7 @@ struct StemBlockArgs {
   const float* ms;      // [32]
   Rq rqs;
   unsigned zs4;         // stem output zero point x 4
-  const long* wdm;      // depthwise [cg(4)][5][lane] x 8 B
+  const v4i* wd64;      // depthwise [cg(2)][3][lane] x 16 B (FusedArgs::wd64 layout)
   const int* bdm;
   const float* mdm;
   Rq rqd;
@@ -37,7 +38,7 @@ struct StemBlockArgs {
 };
 
 constexpr int SB_HW = 18, SB_NPH = SB_HW * SB_HW, SB_NPG = (SB_NPH + 15) / 16;
-constexpr int SB_RROWS = 37, SB_RDW = 30, SB_RST = SB_RDW * 4, SB_PST = 32, SB_SST = 40, SB_DST = 40;
+constexpr int SB_RROWS = 37, SB_RDW = 30, SB_RST = SB_RDW * 4, SB_PST = 32, SB_SST = 48, SB_DST = 40;
 
 // FULL: all three requantisations clamp at the int8 limits (the saturating flavour, no per-element branch)
 template <bool FULL>
@@ -98,7 +99,17 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
     const long wa0 = a.ws[lane], wa1 = a.ws[64 + lane];
     const int4 b0 = *(const int4*)(a.bs + 8 * g), b1 = *(const int4*)(a.bs + 8 * g + 4);
     const float4 m0 = *(const float4*)(a.ms + 8 * g), m1 = *(const float4*)(a.ms + 8 * g + 4);
-    for (int pg = wave; pg < SB_NPG; pg += 4) {
+    // halo pixels outside the stem's output map (tiles on the map border only): bit i <-> pixel group wave + 4i
+    unsigned oob_mask = 0;
+    if (sy0 < 0 || sx0 < 0 || sy0 + SB_HW > a.SH || sx0 + SB_HW > a.SW) {
+      for (int i = 0, pg = wave; pg < SB_NPG; pg += 4, i++) {
+        const int pc = min(pg * 16 + r, SB_NPH - 1);
+        const int hy = pc / SB_HW, hx = pc - hy * SB_HW;
+        const int sy = sy0 + hy, sx = sx0 + hx;
+        if (!(sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW)) oob_mask |= 1u << i;
+      }
+    }
+    for (int i = 0, pg = wave; pg < SB_NPG; pg += 4, i++) {
       const int p = pg * 16 + r;
       const int pc = min(p, SB_NPH - 1);
       const long bv = *(const long*)(P + pc * SB_PST + 8 * g);
@@ -106,37 +117,33 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
       a0 = __builtin_amdgcn_mfma_i32_16x16x32_i8(wa0, bv, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_i32_16x16x32_i8(wa1, bv, a1, 0, 0, 0);
       unsigned q0 = rq_pack_b<FK>(a0, m0, a.rqs), q1 = rq_pack_b<FK>(a1, m1, a.rqs);
-      const int hy = pc / SB_HW, hx = pc - hy * SB_HW;
-      const int sy = sy0 + hy, sx = sx0 + hx;
-      if (!(sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW)) { q0 = a.zs4; q1 = a.zs4; }
+      if ((oob_mask >> i) & 1u) { q0 = a.zs4; q1 = a.zs4; }
       if (p < SB_NPH) *(uint2*)(S + p * SB_SST + 8 * g) = make_uint2(q0, q1);
     }
   }
   __syncthreads();
-  // ---- 3: depthwise 3x3/1 on the matrix pipe: wave -> channel group (wave & 1), output rows 8(wave>>1).. ----
+  // ---- 3: depthwise 3x3/1 on the 16x16x64 MFMA: wave -> channel group (wave & 1), output rows 8(wave>>1).. ----
   {
-    constexpr int KT = 5;
     const int cg = wave & 1;
-    long wreg[KT];
+    v4i wreg[3];
 #pragma unroll
-    for (int mi = 0; mi < KT; mi++) wreg[mi] = a.wdm[((long)cg * KT + mi) * 64 + lane];
+    for (int mi = 0; mi < 3; mi++) wreg[mi] = a.wd64[(cg * 3 + mi) * 64 + lane];
     const int4 bqm = *(const int4*)(a.bdm + 16 * cg + 4 * g);
     const float4 mum = *(const float4*)(a.mdm + 16 * cg + 4 * g);
-    const unsigned char* lane_base = S + 16 * cg + 8 * (g & 1) + r * SB_SST;
-    const int hi_half = g >> 1;
-#pragma unroll 2
-    for (int i = 0; i < 8; i++) {
-      const int py = (wave >> 1) * 8 + i;
-      const unsigned char* pb = lane_base + py * SB_HW * SB_SST;
-      v4i dq = v4i_from(bqm);
+    // lane (r = output column, g = tap column): B operand of instruction m for output row py = 16 channels of halo pixel
+    // (py + m, r + g); g = 3 carries zero weights (it reads one pixel past the window: still inside S)
+    const unsigned char* lane_base = S + (r + g) * SB_SST + 16 * cg + (wave >> 1) * 8 * SB_HW * SB_SST;
 #pragma unroll
-      for (int mi = 0; mi < KT; mi++) {
-        const int ta = 2 * mi, tb = (2 * mi + 1 < 9) ? 2 * mi + 1 : 2 * mi;
-        const int offa = ((ta / 3) * SB_HW + (ta % 3)) * SB_SST, offb = ((tb / 3) * SB_HW + (tb % 3)) * SB_SST;
-        const long bv = *(const long*)(pb + (hi_half ? offb : offa));
-        dq = __builtin_amdgcn_mfma_i32_16x16x32_i8(wreg[mi], bv, dq, 0, 0, 0);
+    for (int i = 0; i < 8; i += 2) {   // two output rows at a time: independent accumulate chains
+      v4i dqa = v4i_from(bqm), dqb = v4i_from(bqm);
+#pragma unroll
+      for (int mi = 0; mi < 3; mi++) {
+        dqa = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], *(const v4i*)(lane_base + (i + mi) * SB_HW * SB_SST), dqa, 0, 0, 0);
+        dqb = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], *(const v4i*)(lane_base + (i + 1 + mi) * SB_HW * SB_SST), dqb, 0, 0, 0);
       }
-      *(unsigned*)(D + (py * 16 + r) * SB_DST + 16 * cg + 4 * g) = rq_pack_b<FK>(dq, mum, a.rqd);
+      const int py = (wave >> 1) * 8 + i;
+      *(unsigned*)(D + (py * 16 + r) * SB_DST + 16 * cg + 4 * g) = rq_pack_b<FK>(dqa, mum, a.rqd);
+      *(unsigned*)(D + ((py + 1) * 16 + r) * SB_DST + 16 * cg + 4 * g) = rq_pack_b<FK>(dqb, mum, a.rqd);
     }
   }
   __syncthreads();
