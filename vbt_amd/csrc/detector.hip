@@ -2096,14 +2096,22 @@ static int fuse_plan(vbt_model* m) {
 // Consecutive small BiFPN nodes -> one launch (node_chain.h).  Groups that sit between two chain members but do not
 // depend on the chain (the lateral 1x1 convs of the first cell) are hoisted in front of it.
 static int chain_nodes(vbt_model* m) {
-  if (!(m->flags & VBT_MODEL_NODE_CHAIN)) return VBT_OK;  // opt-in: measured slower than one launch per node at B = 64
+  // Opt-in (VBT_MODEL_NODE_CHAIN: maps up to 400 pixels, chain chosen without measuring - a plan mode of the parity tests; or
+  // VBT_CHAIN_MAX_HW=<pixels>: offered to the autotuner next to one launch per node).  Measured at B = 64 (round 2): the
+  // 5x5 + 10x10 pair takes 43.5 us as a chain against 5.0 + 6.9 us as two row-band launches - six dependent global round
+  // trips per node on 64 workgroups cost far more than a launch boundary.
+  const bool forced = (m->flags & VBT_MODEL_NODE_CHAIN) != 0;
+  int max_hw = forced ? 400 : 0;
+  if (const char* e = getenv("VBT_CHAIN_MAX_HW")) max_hw = atoi(e);
+  if (max_hw <= 0) return VBT_OK;
+  if (const char* ns = getenv("VBT_SUBSTREAMS")) if (atoi(ns) > 1) return VBT_OK;   // the chain's node list holds whole-batch pointers
   auto small_node = [&](const Group& g) {
     const Alt* fap = tile_alt(g, F_NODE);
     if (!fap) return false;
     const Step& st = fap->steps[0];
     const OpRec& d = m->ops[st.d_op];
     const int HW = st.fa.H * st.fa.W, NB = (st.fa.Cout + 63) / 64;
-    return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= 400 &&
+    return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= max_hw &&
            ((HW + 15) / 16) * NB <= NC_WAVES * NC_MAXU && st.fa.Cin % 4 == 0;
   };
   auto outputs_of = [&](const Group& g, std::set<int>& acc) {
@@ -2148,8 +2156,11 @@ static int chain_nodes(vbt_model* m) {
       for (size_t ci : chain) {
         const Alt& fa = *tile_alt(m->groups[ci], F_NODE);
         const Step& ns = fa.steps[0];
-        each.steps.push_back(ns);
-        for (int t : fa.hidden) { each.hidden.push_back(t); ch.hidden.push_back(t); }
+        // "one launch per node" keeps each member's own default realisation (the row-band kernel where it applies)
+        const Alt& own = m->groups[ci].alts[m->groups[ci].chosen];
+        for (const Step& os : own.steps) each.steps.push_back(os);
+        for (int t : own.hidden) each.hidden.push_back(t);
+        for (int t : fa.hidden) ch.hidden.push_back(t);
         cs.members.push_back(ns);
         cs.op = ns.op;
         cs.d_op = ns.d_op;
@@ -2169,7 +2180,7 @@ static int chain_nodes(vbt_model* m) {
       ch.steps.push_back(cs);
       g.alts.push_back(each);
       g.alts.push_back(ch);
-      g.chosen = 1;
+      g.chosen = forced ? 1 : 0;
       out.push_back(g);
     }
     i = j;

@@ -23,15 +23,16 @@ __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs*
     const int NPG = (HW + 15) >> 4, NB = (a.Cout + 63) >> 6;
     unsigned char* T = nc_smem;
     unsigned char* D = T + PH * PW * TS;
-    const float rcp_w = 1.0f / (float)W;
+    const float rcp_w = frcp(W), rcp_pw = frcp(PW), rcp_nb = frcp(NB);
     // ---- sum stage: T interior <- binary integer ADD(s) of the resampled sources (node_sum4), border <- zx; 4 channels per lane-iteration ----
     {
       const int nd = C >> 2, ndp = TS >> 2;                // dwords per pixel: real channels / whole LDS row
       const unsigned zb4 = (unsigned)(a.zx & 255) * 0x01010101u;
       const bool up2[3] = {H == 2 * a.sh[0] && W == 2 * a.sw[0], H == 2 * a.sh[1] && W == 2 * a.sw[1], H == 2 * a.sh[2] && W == 2 * a.sw[2]};
+      const float rcp_ndp = frcp(ndp);
       for (int i = tid; i < PH * PW * ndp; i += NC_THREADS) {
-        const int p = i / ndp, cd = i - p * ndp;
-        const int py = p / PW, px = p - py * PW;
+        const int p = fdiv_small(i, rcp_ndp), cd = i - p * ndp;
+        const int py = fdiv_small(p, rcp_pw), px = p - py * PW;
         const int iy = py - 1, ix = px - 1;
         unsigned v = zb4;
         if (cd < nd && iy >= 0 && iy < H && ix >= 0 && ix < W) {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs*
       for (int i = 0; i < NC_MAXU; i++) {
         const int u = wave + NC_WAVES * i;
         if (u < NUP) {
-          const int pg = u / NB, nb = u - pg * NB;
+          const int pg = fdiv_small(u, rcp_nb), nb = u - pg * NB;
 #pragma unroll
           for (int k2 = 0; k2 < 2; k2++) {
             const long bv = *(const long*)(D + (pg * 16 + r) * FB_DST + 32 * k2 + 8 * g);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs*
     for (int i = 0; i < NC_MAXU; i++) {
       const int u = wave + NC_WAVES * i;
       if (u >= NUP) continue;
-      const int pg = u / NB, nb = u - pg * NB;
+      const int pg = fdiv_small(u, rcp_nb), nb = u - pg * NB;
       const int slot = pg * 16 + r;
       const int c0 = nb * 64 + 16 * g;
       if (slot >= HW || c0 >= a.Cout) continue;
