@@ -63,14 +63,7 @@ __device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long 
   return (lo | (hi << 8)) ^ 0x80808080u;
 }
 
-__global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem[];
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < 12; i++)
-    if (i < mt.n && (int)blockIdx.x >= mt.start[i]) pi = i;
-  const BandArgs& a = probs[pi];
-  const int local = (int)blockIdx.x - mt.start[pi];
+__device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, unsigned char* bd_smem) {
   const long b = fdiv_small(local, frcp(a.nbands));
   const int band = local - (int)b * a.nbands;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -177,4 +170,20 @@ __global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs
       project_unit(pg, t, *(const v4i*)(WP + (t * 64 + lane) * 16), *(const int4*)(WP + 4096 + 4 * c0), *(const float4*)(WP + 4096 + 256 + 4 * c0));
     }
   }
+}
+
+// Several problems in one grid (the same head layer on all pyramid levels of both heads): the problem list lives in HBM.
+__global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 12; i++)
+    if (i < mt.n && (int)blockIdx.x >= mt.start[i]) pi = i;
+  sepconv_band_body(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+}
+// One problem (a BiFPN node): the arguments travel in the kernel-argument segment, one dependent memory round trip
+// less at the head of a kernel that is a chain of round trips.
+__global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_kernel(BandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+  sepconv_band_body(a, (int)blockIdx.x, bd_smem_dyn);
 }

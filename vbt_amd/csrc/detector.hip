@@ -1003,6 +1003,7 @@ struct Step {
   // F_BAND: SeparableConv / BiFPN node on row bands (band_block.h); members non-empty: several problems in one grid
   BandArgs bd_args;
   BandArgs* d_band = nullptr;   // device copy of the problem list (pointers are those of the whole batch)
+  BandArgs ba;                  // single problem: passed by value
   int band_tiles = 0;           // workgroups per image of this problem
   // F_EXPDW: expand + depthwise on whole images, expanded channels split over workgroups (expdw_block.h; op = depthwise op)
   ExpDwArgs xd;
@@ -1493,6 +1494,7 @@ static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc
   s.lds_bytes = band_lds(a);
   std::vector<BandArgs> one{a};
   if ((rc = upload(m, one, &s.d_band))) return rc;
+  s.ba = a;
   for (int oi : parts)
     if (oi >= 0) {
       s.alg_bytes_per_frame += m->op_steps[oi].alg_bytes_per_frame;
@@ -2734,14 +2736,14 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       static bool attr_set = false;
       if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_one_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
       }
       MultiTiles mt;
       int acc = 0;
       if (s.members.empty()) {
-        mt.n = 1;
-        mt.start[0] = 0;
-        acc = B * s.band_tiles;
+        sepconv_band_one_kernel<<<dim3((unsigned)(B * s.band_tiles)), BD_THREADS, s.lds_bytes, st>>>(s.ba);
+        break;
       } else {
         mt.n = (int)s.members.size();
         for (int i = 0; i < mt.n; i++) {
