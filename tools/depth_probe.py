@@ -1,6 +1,7 @@
-"""Scratch: one configuration per process: GPU_MAX_HW_QUEUES x depth x tracker mode."""
+"""Steady-state ms/step of one configuration per process: python tools/depth_probe.py <GPU_MAX_HW_QUEUES> <depth> <detect|own|inline>
+(the queue-count / pipeline-depth measurements)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 q, depth, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 os.environ["GPU_MAX_HW_QUEUES"] = q

@@ -1,8 +1,8 @@
-"""Scratch: where do the 1.3 ms of fixed cost in a 20-step timed region go?"""
+"""Where the fixed cost of a 20-step timed region goes: enqueue / drain / close per repetition, K = 20, 40, 80."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("VBT_PLAN_FILE", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "plan_lite0"))
+os.environ.setdefault("VBT_PLAN_FILE", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "plan_lite0"))
 import numpy as np, torch
 import bench
 from vbt_amd.track import Pipeline

@@ -1,3 +1,4 @@
+"""Per-kernel table of one forward from two rocprofv3 --pmc passes (tools/profile_session.sh layout): python tools/kernel_table.py gpurun_out/<tag>"""
 import csv, collections, sys
 d = sys.argv[1]
 def load(path):
