@@ -1189,7 +1189,10 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     a.we = es.wp; a.be = es.bias; a.me = es.mult; a.KSe = es.KS;
     a.ze = tdin.zero_point; a.loe = eop.act_min; a.hie = eop.act_max;
     a.rqe = make_rq(a.ze, a.loe, a.hie);
-    a.T0S = es.KS * 32 + 8;
+    // input tile rows hold the real channels (8-byte granules) + 8 bytes of bank spread, not the K padding of the expand
+    // (KS * 32): the B-operand reads of the padded K steps run into the next pixel's bytes, which meet zero weights (the
+    // last pixel's run into the E tile).  b1: 40 -> 24 bytes, b4 / b5: 72 -> 48 - LDS per workgroup sets the occupancy here.
+    a.T0S = ((tin.c + 7) & ~7) + 8;
   } else {
     a.T0S = Cp + 16;
   }
@@ -2643,7 +2646,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         a.tiles_y = (a.OH + a.TY - 1) / a.TY;
         const int TXp_ = (a.TX + 3) & ~3;
         const int NPh_ = ((TXp_ - 1) * dop.stride + dop.k) * ((a.TY - 1) * dop.stride + dop.k);
-        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * FB_EST + 15) & ~15) + 128 * FB_DST;
+        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * (nt3 ? 48 : FB_EST) + 15) & ~15) + 128 * FB_DST;
         grid = dim3((unsigned)((long)B * a.tiles_x * a.tiles_y));
         if (a.OW < 16 || a.OH < 8 || !a.wd64) { set_error("fused_mbconv: the 128-pixel variant needs maps of at least 16 x 8"); return VBT_ERR_ARG; }
 #define FB_P2(KK, S, NBP, KSE)                                                                                      \
@@ -2669,9 +2672,9 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       }
       // 64-pixel tiles of exactly 8 x 8 outputs, K <= 64, <= 128 output channels: depthwise on the 16x16x64 MFMA (DW64)
       const bool dw64 = ex && mdw && a.wd64 && a.TX == 8 && a.TY == 8 && (a.KSe == 1 || a.KSe == 2) && s.nbp <= 2 && !getenv("VBT_NO_DW64");
-      if (dw64 && nt3) {   // E rows are 80 bytes in the DW64 kernels
+      if (dw64 && nt3) {   // E rows are 48 bytes in the 48-channel DW64 kernels
         const int NPh_ = ((8 - 1) * dop.stride + dop.k) * ((8 - 1) * dop.stride + dop.k);
-        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * FB_EST + 15) & ~15) + 64 * FB_DST;
+        lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * 48 + 15) & ~15) + 64 * FB_DST;
       }
 #define FB_DW64(KK, S, NBP)                                                                                \
   do {                                                                                                     \

@@ -125,7 +125,9 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   unsigned char* E = T0 + ((NPh * a.T0S + 15) & ~15);
   // 48-channel chunks keep E rows at 72 bytes: fewer bank conflicts in the depthwise reads (18-dword pixel stride: conflict-
   // free at stride 1, 2-way at stride 2; 80 bytes gives 2-way / 4-way) and less LDS per workgroup
-  constexpr int EST = (EXPAND && NT == 3 && !DW64) ? 72 : FB_EST;   // DW64 reads 16-byte groups: rows stay 16-byte aligned
+  // DW64 reads 16-byte groups, so its rows stay 16-byte aligned: 48 bytes for 48-channel chunks (conflict-free b128 reads at
+  // stride 1, 3-dword-skewed conflict-free writes, and 40 % less LDS than 80-byte rows: one more workgroup per CU on b1-b3)
+  constexpr int EST = (EXPAND && NT == 3) ? (DW64 ? 48 : 72) : FB_EST;
   unsigned char* D = E + (EXPAND ? ((NPh * EST + 15) & ~15) : 0);
   // SeparableConv / node / head tiles whose depthwise input is ONE 64-channel chunk (BiFPN width 64): the projection
   // weights and its bias / multipliers are copied into LDS while the input tile loads, so the projection and the epilogue
@@ -380,7 +382,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
     if constexpr (DW64) {
       constexpr int TXP = 8 * PPW, HWX = (TXP - 1) * S + KK;
       constexpr int KT64 = KK == 3 ? 3 : 7;
-      constexpr int PGS = (16 / TXP) * S * HWX * FB_EST;   // slot group pg -> pg + 1
+      constexpr int PGS = (16 / TXP) * S * HWX * EST;   // slot group pg -> pg + 1
       if (NT == 4 || wave < NT) {   // wave = 16-channel group of the chunk (48-channel chunks: wave 3 sits this stage out)
         const v4i* wm = a.wd64 + ((long)(c * NT + wave) * KT64) * 64 + lane;
         v4i wreg[KT64];
@@ -389,15 +391,15 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
         const int4 bqm = *(const int4*)(a.bdm + c * CH + 16 * wave + 4 * g);
         const float4 mum = *(const float4*)(a.md + c * CH + 16 * wave + 4 * g);
         const int hb = TXP == 8 ? ((r >> 3) * S * HWX + (r & 7) * S) : r * S;   // window origin of slot r of group 0
-        const unsigned char* baseH = E + hb * FB_EST + 16 * wave + g * FB_EST;          // g = column of the tap
-        const unsigned char* baseV = E + hb * FB_EST + 16 * wave + g * (HWX * FB_EST);  // g = row of the tap (5x5, column 4)
+        const unsigned char* baseH = E + hb * EST + 16 * wave + g * EST;          // g = column of the tap
+        const unsigned char* baseV = E + hb * EST + 16 * wave + g * (HWX * EST);  // g = row of the tap (5x5, column 4)
 #pragma unroll
         for (int pg = 0; pg < 4 * PPW; pg += 2) {   // two slot groups at a time: independent accumulate chains
           v4i dqa = v4i_from(bqm), dqb = v4i_from(bqm);
 #pragma unroll
           for (int mi = 0; mi < KT64; mi++) {
             const unsigned char* bp = (KK == 5 && mi == 5) ? baseV : baseH;
-            const int off = KK == 3 ? mi * HWX * FB_EST : (mi < 5 ? mi * HWX * FB_EST : (mi == 5 ? 4 * FB_EST : (4 * HWX + 4) * FB_EST));
+            const int off = KK == 3 ? mi * HWX * EST : (mi < 5 ? mi * HWX * EST : (mi == 5 ? 4 * EST : (4 * HWX + 4) * EST));
             const v4i bva = *(const v4i*)(bp + pg * PGS + off);
             const v4i bvb = *(const v4i*)(bp + (pg + 1) * PGS + off);
             dqa = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], bva, dqa, 0, 0, 0);
