@@ -1775,7 +1775,11 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
   a.PH = std::max((a.OH - 1) * dop.stride + dop.k, a.pad_t + a.H);
   a.PW = std::max((a.OW - 1) * dop.stride + dop.k, a.pad_l + a.W);
   const int KS64 = (tin.c + 63) / 64, K = tin.c, Ce = te.c, nch = (Ce + 63) / 64, kk = dop.k * dop.k, KT = (kk + 3) / 4;
-  a.T0S = KS64 * 64 + 32;   // 160 / 224-byte rows: the expand's 16-byte B-operand reads (16 pixels x 4 k-groups) are bank-conflict-free (144 / 208 are 2-way)
+  // input rows hold the real channels (16-byte granules), not the K padding: the B-operand reads of the padded K run into the
+  // next pixel's bytes and meet zero weights (the last pixel's into the E tile).  An odd number of 16-byte granules per row
+  // makes the 16-pixel b128 reads bank-conflict-free (80, 112, 208 bytes for 80, 112, 192 channels; was 160 / 224): the
+  // 20x20 blocks free 32 KB of LDS per CU for the other forwards in flight.
+  a.T0S = ((tin.c + 15) / 16 | 1) * 16;
   a.nchunks = nch;
   a.cpw = 1;
   const int8_t* we = (const int8_t*)(m->blob.data() + eop.w_off);

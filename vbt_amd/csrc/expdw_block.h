@@ -11,7 +11,7 @@
 //     64 images x (7.5 .. 18 chunks / cpw) workgroups;
 //   * the expand runs on the real pixels only and lands in an LDS copy of the image bordered by its zero point, so SAME
 //     padding costs nothing; the 6x expanded tensor never reaches HBM, the depthwise output (1/k^2 of the MACs) does.
-// LDS:  T0 [H*W][T0S]      block input, all channels (K padded to 64-byte steps: the pad multiplies zero weights)
+// LDS:  T0 [H*W][T0S]      block input, real channels only (the reads of the K padding run into the next pixel: zero weights)
 //       E  [PH*PW][80]     one 64-channel chunk of the expanded tensor inside a border of its zero point
 //       D  [OH*OW (16-padded)][80]  one chunk of the depthwise output, copied out with 16-byte stores
 // 16 wavefronts.  Both stages run on the 16x16x64 int8 MFMA; wave w keeps the operands of 16-channel tile (w & 3) in
@@ -29,7 +29,7 @@ struct ExpDwArgs {
   int H, W, Cin, OH, OW, Ce;
   int PW, PH;        // bordered E image
   int pad_t, pad_l;
-  int T0S;           // KS64 * 64 + 32
+  int T0S;           // odd multiple of 16 bytes >= Cin
   int nchunks, cpw;  // 64-channel chunks in all / per workgroup
   const v4i* we;     // expand weights [chunk][ks][t][lane] x 16 B: row i of tile t = channel 64c + 16t + i, k = 64ks + 16g + j
   const int* be;     // bias with the input zero point folded, padded to 64 * nchunks
