@@ -95,6 +95,13 @@ int vbt_model_read_tensor(vbt_model* m, int tensor_id, int B, int8_t* host_out);
 int vbt_detect_async(vbt_model* m, const uint8_t* frames_dev, int B, void* stream,
                      float* boxes_dev, float* scores_dev, float* classes_dev, int32_t* counts_dev);
 
+/* Streams for a pipeline that keeps several forwards in flight (the reference runs one interpreter.invoke() at a time,
+ * odt.py:58-61; there is no reference counterpart).  A HIP stream is bound to a hardware queue at its first command,
+ * round-robin: the stream returned here has already run one empty launch, so streams created back to back use distinct
+ * queues, whatever a framework's stream pool has been used for before. */
+int vbt_stream_create(int device, void** stream_out);
+int vbt_stream_destroy(void* stream);
+
 /* preprocess_image (reference odt.py:10-19): bilinear resize (half-pixel centres, float32) of
  * uint8 [B,H,W,3] frames to [B,h,w,3] + truncating uint8 cast; swap_rb != 0 also swaps channels 0
  * and 2 (cv2 BGR -> RGB, reference track.py:171).  src/dst are host or device pointers. */

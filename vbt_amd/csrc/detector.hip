@@ -3256,6 +3256,28 @@ int vbt_model_read_tensor(vbt_model* m, int id, int B, int8_t* host_out) {
   return VBT_OK;
 }
 
+// A HIP stream gets its hardware queue at its FIRST command, round-robin over GPU_MAX_HW_QUEUES (rocprofv3 Queue_Id).  Streams
+// drawn from a framework's pool may have been used before, so a pipeline's streams can land on one queue and serialise
+// (measured: 89 k -> 58 k frames/s).  Streams created here run one empty launch at once: streams created back to back sit on
+// consecutive queues.
+__global__ void stream_touch_kernel() {}
+int vbt_stream_create(int device, void** stream_out) {
+  if (!stream_out) { set_error("vbt_stream_create: NULL argument"); return VBT_ERR_ARG; }
+  VBT_HIP_CHECK(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  VBT_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  stream_touch_kernel<<<1, 64, 0, st>>>();
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { (void)hipStreamDestroy(st); set_error("vbt_stream_create: %s", hipGetErrorString(e)); return VBT_ERR_HIP; }
+  *stream_out = (void*)st;
+  return VBT_OK;
+}
+int vbt_stream_destroy(void* stream) {
+  if (!stream) return VBT_OK;
+  VBT_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return VBT_OK;
+}
+
 int vbt_resize_frames(const uint8_t* src, int B, int H, int W, int src_on_device, uint8_t* dst, int h, int w, int dst_on_device,
                       int swap_rb, int device, void* stream) {
   if (!src || !dst || B < 1 || H < 1 || W < 1 || h < 1 || w < 1) { set_error("vbt_resize_frames: bad argument"); return VBT_ERR_ARG; }

@@ -81,6 +81,9 @@ def export_dataframe(data, src_name, model_path, df_dir=None, write=True):
     return df, int(max_distance_id), df_path
 
 
+_STREAMS = {}   # device -> {"streams": [torch.cuda.ExternalStream], "free": [indices]}: see Pipeline._new_stream
+
+
 class Pipeline:
     """n clips processed frame-wise: step(frames[n,H,W,3] on the device) enqueues detect+NMS for this frame
     set and the tracker step of the PREVIOUS one; finish() drains, selects each clip's export id and runs the
@@ -119,8 +122,12 @@ class Pipeline:
                       for _ in range(self.depth)]
         self._times = [np.zeros(n, np.float64) for _ in range(self.depth)]
         self._maps = [None] * self.depth             # per-slot clip maps of the steps in flight
-        self._det_streams = [torch.cuda.Stream(device=tdev) for _ in range(self.depth)]
-        self._trk_stream = torch.cuda.Stream(device=tdev)
+        # The pipeline's own HIP streams, created back to back (detector slots, tracker, copy): each is bound to its
+        # hardware queue at creation (vbt_stream_create), so they sit on distinct queues.  Streams from torch's pool may have
+        # been used before and then share a queue with a neighbour - measured 89 k -> 58 k frames/s.
+        self._own_streams = []
+        self._det_streams = [self._new_stream(tdev) for _ in range(self.depth)]
+        self._trk_stream = self._new_stream(tdev)
         # Where the OC-SORT step of a frame runs.  "own": on the tracker stream (it waits for the slot's detections).  "inline":
         # at the end of the slot's own stream, after an event wait on the previous frame's tracker step.  The GPU runs four
         # hardware queues side by side; a fifth active one costs a quarter of the throughput (MI355X, 8 HIP queues: depth 3 +
@@ -141,7 +148,35 @@ class Pipeline:
         self._stage = [None] * (self.depth + 2)
         self._stage_free = [None] * (self.depth + 2)
         self._stage_idx = 0
-        self._copy_stream = torch.cuda.Stream(device=tdev)
+        self._copy_stream = self._new_stream(tdev)
+
+    def _new_stream(self, tdev):
+        torch = self._torch
+        if os.environ.get("VBT_TORCH_POOL_STREAMS") == "1":
+            return torch.cuda.Stream(device=tdev)
+        # Streams are kept for the life of the process and handed out again when a pipeline goes away (lowest index first, so
+        # a pipeline's streams stay neighbours in creation order = on distinct hardware queues).  They are never destroyed:
+        # torch's caching allocator may still hold record_stream() references to them.
+        pool = _STREAMS.setdefault(self._dev, {"streams": [], "free": []})
+        if pool["free"]:
+            i = min(pool["free"])
+            pool["free"].remove(i)
+        else:
+            import ctypes
+            h = ctypes.c_void_p()
+            _lib.check(_lib.lib().vbt_stream_create(self._dev, ctypes.byref(h)))
+            pool["streams"].append(torch.cuda.ExternalStream(h.value, device=tdev))
+            i = len(pool["streams"]) - 1
+        self._own_streams.append(i)
+        return pool["streams"][i]
+
+    def __del__(self):
+        try:
+            idx, self._own_streams = getattr(self, "_own_streams", []), []
+            if idx and _STREAMS is not None:
+                _STREAMS[self._dev]["free"].extend(idx)
+        except Exception:
+            pass
 
     def _enqueue_tracker(self, k):
         if self._trk_inline:
