@@ -125,6 +125,9 @@ typedef struct {
   double ms, algorithmic_bytes, macs;
 } vbt_step_time;
 int vbt_model_profile_steps(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream, vbt_step_time* out, int cap, int* n);
+/* Measurement: each plan step `reps` times on one stream (single_ms, per launch) and on `nstreams` streams at once
+ * (conc_ms, wall time per launch): how much of a step the other forwards in flight can hide. */
+int vbt_model_profile_overlap(vbt_model* m, int B, int reps, int nstreams, float* single_ms, float* conc_ms, int cap, int* n);
 
 /* Time each kernel family with HIP events on `stream` over `reps` forwards of batch B
  * (frames must be device-resident). ms_out[i] = average milliseconds per forward spent in

@@ -3388,4 +3388,35 @@ int vbt_model_profile_steps(vbt_model* m, const uint8_t* frames_dev, int B, int 
   return rc;
 }
 
+// Measurement: every plan step launched `reps` times back to back on ONE stream, then `reps` times on each of `nstreams`
+// streams at once.  conc_ms[i] (time per launch with the streams racing) against single_ms[i] says how much of step i a
+// second and third forward in flight can hide: equal -> the kernel saturates a resource, 1/nstreams -> pure latency.
+int vbt_model_profile_overlap(vbt_model* m, int B, int reps, int nstreams, float* single_ms, float* conc_ms, int cap, int* n) {
+  if (!m || !single_ms || !conc_ms || !n || reps < 1 || nstreams < 1 || nstreams > 8) { set_error("bad argument"); return VBT_ERR_ARG; }
+  if (B < 1 || B > m->max_batch) { set_error("bad batch"); return VBT_ERR_CAPACITY; }
+  const int ns = (int)m->steps.size();
+  if (cap < ns) { set_error("%d plan steps, buffer holds %d", ns, cap); return VBT_ERR_CAPACITY; }
+  std::vector<hipStream_t> ss(nstreams, nullptr);
+  for (auto& st : ss) VBT_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  int rc = VBT_OK;
+  for (int i = 0; i < ns && rc == VBT_OK; i++) {
+    const Step& s = m->steps[i];
+    for (int pass = 0; pass < 2 && rc == VBT_OK; pass++) {
+      const int k = pass == 0 ? 1 : nstreams;
+      for (int j = 0; j < k && rc == VBT_OK; j++) rc = launch_step(m, s, B, ss[j], m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+      if (rc) break;
+      VBT_HIP_CHECK(hipDeviceSynchronize());
+      auto t0 = std::chrono::steady_clock::now();
+      for (int r = 0; r < reps; r++)
+        for (int j = 0; j < k; j++) (void)launch_step(m, s, B, ss[j], m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+      VBT_HIP_CHECK(hipDeviceSynchronize());
+      const float ms = (float)(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (reps * k));
+      (pass == 0 ? single_ms : conc_ms)[i] = ms;
+    }
+  }
+  for (auto& st : ss) (void)hipStreamDestroy(st);
+  *n = ns;
+  return rc;
+}
+
 }  // extern "C"
