@@ -63,7 +63,12 @@ __device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long 
   return (lo | (hi << 8)) ^ 0x80808080u;
 }
 
+// NW waves per workgroup: 16 for a BiFPN node (one or two workgroups per image: the per-wave chain of units must be short), 8 for
+// the head layers (1280+ bands per launch: 16-wave workgroups fill every wave slot of a CU with two of them, so a third forward
+// in flight cannot co-reside; 8 waves on bands of <= 240 pixels interleave twice as many phases - +1.3 % end to end).
+template <int NW>
 __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, unsigned char* bd_smem) {
+  constexpr int nwaves = NW, nthreads = 64 * NW;
   const long b = fdiv_small(local, frcp(a.nbands));
   const int band = local - (int)b * a.nbands;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -75,13 +80,13 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const int NT = (a.Cout + 15) >> 4;
 
   // ---- stage L: band + border -> T0; projection weights / bias / multipliers -> LDS ----
-  for (int i = tid; i < NT * 64; i += BD_THREADS) *(v4i*)(WP + 16 * i) = a.wp[i];
+  for (int i = tid; i < NT * 64; i += nthreads) *(v4i*)(WP + 16 * i) = a.wp[i];
   if (tid < 16) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.bp + 16 * tid);
   else if (tid < 32) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.mp + 16 * (tid - 16));
   const float rcp_pw = frcp(PW);
   if (a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
-    for (int i = tid; i < NPh * 16; i += BD_THREADS) {   // 4 channels per lane-iteration
+    for (int i = tid; i < NPh * 16; i += nthreads) {   // 4 channels per lane-iteration
       const int p = i >> 4, cd = i & 15;
       const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
       const int iy = y0 + hy - 1, ix = hx - 1;
@@ -102,7 +107,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   } else {
     const int8_t* xb = a.x + b * (long)a.H * a.W * 64;
     const uint4 z4 = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
-    for (int i = tid; i < NPh * 4; i += BD_THREADS) {    // 16 bytes per lane-iteration
+    for (int i = tid; i < NPh * 4; i += nthreads) {    // 16 bytes per lane-iteration
       const int p = i >> 2, sg = i & 3;
       const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
       const int iy = y0 + hy - 1, ix = hx - 1;
@@ -127,7 +132,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const float rcp_w = frcp(a.W);
   __syncthreads();
   // ---- stage D: depthwise; unit = (output pixel group, channel group cg) ----
-  for (int pg = wave >> 2; pg < NPG; pg += BD_WAVES / 4) {
+  for (int pg = wave >> 2; pg < NPG; pg += nwaves / 4) {
     const int slot = pg * 16 + r, sc = min(slot, NPo - 1);
     const int py = fdiv_small(sc, rcp_w), px = sc - py * a.W;
     const unsigned char* pb = T0 + (py * PW + px) * BD_ST + 16 * cg;
@@ -162,9 +167,9 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
     const v4i wv = *(const v4i*)(WP + (t * 64 + lane) * 16);
     const int4 bb = *(const int4*)(WP + 4096 + 4 * c0);
     const float4 mm = *(const float4*)(WP + 4096 + 256 + 4 * c0);
-    for (int pg = wave >> 2; pg < NPG; pg += BD_WAVES / 4) project_unit(pg, t, wv, bb, mm);
+    for (int pg = wave >> 2; pg < NPG; pg += nwaves / 4) project_unit(pg, t, wv, bb, mm);
   } else {
-    for (int u = wave; u < NU; u += BD_WAVES) {
+    for (int u = wave; u < NU; u += nwaves) {
       const int pg = fdiv_small(u, rcp_nt), t = u - pg * NT;
       const int c0 = 16 * t + 4 * g;
       project_unit(pg, t, *(const v4i*)(WP + (t * 64 + lane) * 16), *(const int4*)(WP + 4096 + 4 * c0), *(const float4*)(WP + 4096 + 256 + 4 * c0));
@@ -173,17 +178,18 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 }
 
 // Several problems in one grid (the same head layer on all pyramid levels of both heads): the problem list lives in HBM.
-__global__ __launch_bounds__(BD_THREADS) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+constexpr int BD_HEAD_WAVES = 8, BD_HEAD_MAXPX = 240;
+__global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < 12; i++)
     if (i < mt.n && (int)blockIdx.x >= mt.start[i]) pi = i;
-  sepconv_band_body(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+  sepconv_band_body<BD_HEAD_WAVES>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
 // One problem (a BiFPN node): the arguments travel in the kernel-argument segment, one dependent memory round trip
 // less at the head of a kernel that is a chain of round trips.
 __global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_kernel(BandArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
-  sepconv_band_body(a, (int)blockIdx.x, bd_smem_dyn);
+  sepconv_band_body<BD_WAVES>(a, (int)blockIdx.x, bd_smem_dyn);
 }

@@ -1580,7 +1580,16 @@ static int batch_heads(vbt_model* m) {
       each.steps.push_back(fs);
       for (int t : ta->hidden) { each.hidden.push_back(t); multi.hidden.push_back(t); bandm.hidden.push_back(t); }
       if (const Alt* ba = band_alt(src)) {
-        const Step& b1 = ba->steps[0];
+        Step b1 = ba->steps[0];
+        {   // the head grid runs 8-wave workgroups on shorter bands (band_block.h)
+          BandArgs& ha = b1.bd_args;
+          const int nbh = std::max(1, (ha.H * ha.W + BD_HEAD_MAXPX - 1) / BD_HEAD_MAXPX);
+          ha.rows = (ha.H + nbh - 1) / nbh;
+          ha.nbands = (ha.H + ha.rows - 1) / ha.rows;
+          b1.band_tiles = ha.nbands;
+          b1.lds_bytes = band_lds(ha);
+          b1.ba = ha;
+        }
         bs.members.push_back(b1);
         bargs.push_back(b1.bd_args);
         bs.lds_bytes = std::max(bs.lds_bytes, b1.lds_bytes);
@@ -2759,7 +2768,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         }
       }
       mt.start[mt.n] = acc;
-      sepconv_band_kernel<<<dim3((unsigned)acc), BD_THREADS, s.lds_bytes, st>>>(s.d_band, mt);
+      sepconv_band_kernel<<<dim3((unsigned)acc), 64 * BD_HEAD_WAVES, s.lds_bytes, st>>>(s.d_band, mt);
       break;
     }
     case F_EXPDW: {
