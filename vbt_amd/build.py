@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvbt_hip.so")
 SOURCES = ["detector.hip", "tracker.hip"]
-FLAGS = (["-DFB_MINW=" + os.environ["VBT_FB_MINW"]] if os.environ.get("VBT_FB_MINW") else []) + ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = (["-DFB_MINW=" + os.environ["VBT_FB_MINW"]] if os.environ.get("VBT_FB_MINW") else []) + os.environ.get("VBT_EXTRA_CXXFLAGS", "").split() + ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
          # MFMA results land in VGPRs (gfx90a+ unified register file): the requantisation epilogues read the
          # accumulators directly instead of through one v_accvgpr_read per element

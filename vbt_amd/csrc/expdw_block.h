@@ -14,13 +14,19 @@
 // LDS:  T0 [H*W][T0S]      block input, real channels only (the reads of the K padding run into the next pixel: zero weights)
 //       E  [PH*PW][80]     one 64-channel chunk of the expanded tensor inside a border of its zero point
 //       D  [OH*OW (16-padded)][80]  one chunk of the depthwise output, copied out with 16-byte stores
-// 16 wavefronts.  Both stages run on the 16x16x64 int8 MFMA; wave w keeps the operands of 16-channel tile (w & 3) in
-// registers and walks the pixel groups (w >> 2) + 4i.  Depthwise on the matrix pipe as in fused_block.h, four taps per
+// 8 wavefronts (XD_WAVES).  Both stages run on the 16x16x64 int8 MFMA; wave w keeps the operands of 16-channel tile (w & 3) in
+// registers and walks the pixel groups (w >> 2) + 2i.  Depthwise on the matrix pipe as in fused_block.h, four taps per
 // instruction: out[c][p] = sum_t W'[c][(t,c')] X[(t,c')][p], W' = w[t][c] delta(c,c'), exact int32.
 // Arithmetic identical to the per-op kernels: same integer accumulations, same single-op float requantisation.
 #pragma once
 
-constexpr int XD_WAVES = 16, XD_THREADS = 64 * XD_WAVES;
+// Waves per workgroup.  Measured end to end with three forwards in flight (A/B of two builds on one box): 16 waves 90.2 k
+// frames/s, 8 waves 91.9 k (92.5 k with the chunks per workgroup re-tuned), 4 waves 86.6 k.  A 16-wave workgroup is faster alone
+// (15 vs 21 us on b6) but holds every SIMD of its CU at each of its barriers; 8 waves leave issue slots to the other forwards.
+#ifndef VBT_XD_WAVES
+#define VBT_XD_WAVES 8
+#endif
+constexpr int XD_WAVES = VBT_XD_WAVES, XD_THREADS = 64 * XD_WAVES;
 constexpr int XD_EST = 80;   // bytes per pixel of E and D rows (64 + 16: bank spread, 16-byte aligned)
 
 struct ExpDwArgs {
