@@ -15,7 +15,10 @@
 // instruction: three instructions for 3x3).  Arithmetic identical to the per-op kernels.
 #pragma once
 
-constexpr int BD_WAVES = 16, BD_THREADS = 64 * BD_WAVES;
+#ifndef VBT_BD_WAVES
+#define VBT_BD_WAVES 16
+#endif
+constexpr int BD_WAVES = VBT_BD_WAVES, BD_THREADS = 64 * BD_WAVES;
 constexpr int BD_ST = 80;   // bytes per pixel row of T0 and D
 
 struct BandArgs {
