@@ -130,10 +130,11 @@ class Pipeline:
         self._trk_stream = self._new_stream(tdev)
         # Where the OC-SORT step of a frame runs.  "own": on the tracker stream (it waits for the slot's detections).  "inline":
         # at the end of the slot's own stream, after an event wait on the previous frame's tracker step.  The GPU runs four
-        # hardware queues side by side; a fifth active one costs a quarter of the throughput (MI355X, 8 HIP queues: depth 3 +
-        # tracker stream 87.0 k frames/s, inline 87.5 k; depth 4 + tracker stream 75.8 k, inline 76.4 k - a step that sits in
-        # a detector stream's chain lengthens every forward).  Default: own stream up to depth 3, inline from depth 4.
-        mode = os.environ.get("VBT_TRACKER_STREAM", "inline" if self.depth >= 4 else "own")
+        # hardware queues side by side; a fifth active one costs a quarter of the throughput.  Inline keeps the pipeline on
+        # `depth` queues: at depth 3 that leaves the fourth to the copy stream of the host-fed mode (MI355X, 64 clips: 92.9 k
+        # vs 92.4 k frames/s device-resident, 77.8 k vs 71.7 k with frames from pinned host memory).  Depth 4 is slower either
+        # way (81-83 k).  Default: inline from depth 3, own stream below (there the tracker overlaps the next forward).
+        mode = os.environ.get("VBT_TRACKER_STREAM", "inline" if self.depth >= 3 else "own")
         if mode not in ("own", "inline"):
             raise ValueError("VBT_TRACKER_STREAM must be 'own' or 'inline'")
         self._trk_inline = mode == "inline"
