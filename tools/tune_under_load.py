@@ -76,6 +76,8 @@ for ln, text in enumerate(lines, 1):
     elif ns == 2 and var[0] in (1, 2, 3, 4, 6):                   # expand + depthwise: chunks per workgroup
         for c in (1, 2, 3, 4, 6):
             opts.add(f"{alt} 2 {c} {var[1]}")
+        for v in (-1, 2):                                        # the projection behind it: K-streaming / split-K variant
+            opts.add(f"{alt} 2 {var[0]} {v}")
     opts.discard(text)
     if opts:
         cands.append((ln, sorted(opts)))

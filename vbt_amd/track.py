@@ -150,6 +150,21 @@ class Pipeline:
         self._stage_free = [None] * (self.depth + 2)
         self._stage_idx = 0
         self._copy_stream = self._new_stream(tdev)
+        # Self-check: every slot runs its whole plan on a blank batch before the first real frame, so a plan the kernels
+        # reject (LDS budget, tile shape) fails here and not in the middle of a clip; the first real step then also finds
+        # code objects, arenas and GPU clocks warm.  Detector only: no tracker state is touched.
+        n_check = int(os.environ.get("VBT_PIPELINE_SELFCHECK", "1"))
+        if n_check > 0:
+            size = int(self.interpreter.get_input_details()[0]["shape"][1])
+            blank = torch.zeros((self.n, size, size, 3), dtype=torch.uint8, device=tdev)
+            torch.cuda.current_stream().synchronize()
+            for _ in range(n_check):
+                for k in range(self.depth):
+                    b, s_, c, cnt = self._bufs[k]
+                    _lib.check(_lib.lib().vbt_detect_async(self.interpreters[k].handle, blank.data_ptr(), self.n,
+                                                           self._det_streams[k].cuda_stream, b.data_ptr(), s_.data_ptr(), c.data_ptr(), cnt.data_ptr()))
+            for S in self._det_streams:
+                S.synchronize()
 
     def _new_stream(self, tdev):
         torch = self._torch
