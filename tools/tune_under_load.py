@@ -29,7 +29,12 @@ def score(lines, reps=2, K=300):
         f.write("\n".join(lines) + "\n")
     before = open(TRIAL + ".b64.f0").read()
     os.environ["VBT_PLAN_FILE"] = TRIAL
-    pipe = Pipeline(bench.MODEL, n, max_frames=K + 40, fps=60.0, detection_treshold=0.5, device=0, rows_per_frame=8)
+    try:
+        pipe = Pipeline(bench.MODEL, n, max_frames=K + 40, fps=60.0, detection_treshold=0.5, device=0, rows_per_frame=8)
+    except Exception as e:                              # the creation-time self-check rejects the plan
+        print(f"    rejected: {str(e)[:90]}", flush=True)
+        torch.cuda.synchronize()
+        return None
     if open(TRIAL + ".b64.f0").read() != before:
         del pipe
         return None                                  # the library did not accept the plan and re-tuned
