@@ -2475,14 +2475,18 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
           default: launch_pw_a<4>(MS, grid, st, x, s.wp64, e, ra, out, M, K, N, s.NB, nb_per_y); break;
         }
       } else if (s.variant == 2) {  // split-K over the 4 waves of a workgroup
-        int nbt = std::min(s.NB, 2);
+        // one 64-channel block per workgroup (16 KB of LDS for the cross-wave reduction, twice the workgroups) rather than two
+        // (32 KB): +1.4 % end to end with three forwards in flight - the workgroups of one launch then fit the CUs in one round
+        static const int nbt_max = getenv("VBT_PWC_NBT") ? atoi(getenv("VBT_PWC_NBT")) : 1;
+        int nbt = std::min(s.NB, nbt_max);
         dim3 grid((unsigned)((M + 15) / 16), (unsigned)((s.NB + nbt - 1) / nbt));
         if (nbt == 1) pw_c_kernel<1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
         else pw_c_kernel<2><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
       } else {
         long waves = (M + 15) / 16;
         unsigned gx = (unsigned)((waves + 3) / 4);
-        int nbt = std::min(s.NB, 4);
+        static const int nbt_cap_b = getenv("VBT_PWB_NBT") ? atoi(getenv("VBT_PWB_NBT")) : 4;
+        int nbt = std::min(s.NB, nbt_cap_b);
         if (gx < 512 && nbt > 2) nbt = 2;  // more workgroups for the low-resolution layers
         if (gx < 128) nbt = 1;
         dim3 grid(gx, (s.NB + nbt - 1) / nbt);
