@@ -27,7 +27,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch initialises HIP (see vbt_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # before torch initialises HIP (see vbt_amd/__init__.py)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # The kernel plan tuned on an MI355X at B = 64 is pinned so that every run (and the committed rocprofv3 / PMC

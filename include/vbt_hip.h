@@ -101,6 +101,9 @@ int vbt_detect_async(vbt_model* m, const uint8_t* frames_dev, int B, void* strea
  * queues, whatever a framework's stream pool has been used for before. */
 int vbt_stream_create(int device, void** stream_out);
 int vbt_stream_destroy(void* stream);
+/* *shared = 1 when the two streams sit on one hardware queue (their kernels cannot overlap): a single wave spins `us`
+ * microseconds on each and the pair is timed.  The device must be otherwise idle. */
+int vbt_streams_share_queue(void* a, void* b, int us, int* shared);
 
 /* preprocess_image (reference odt.py:10-19): bilinear resize (half-pixel centres, float32) of
  * uint8 [B,H,W,3] frames to [B,h,w,3] + truncating uint8 cast; swap_rb != 0 also swaps channels 0

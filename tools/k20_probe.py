@@ -1,7 +1,7 @@
 """Where the fixed cost of a 20-step timed region goes: enqueue / drain / close per repetition, K = 20, 40, 80."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 os.environ.setdefault("VBT_PLAN_FILE", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "plan_lite0"))
 import numpy as np, torch
 import bench

@@ -8,7 +8,7 @@ library re-writing the file and is skipped."""
 import os, sys, time, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 import numpy as np, torch
 import bench
 from vbt_amd.track import Pipeline

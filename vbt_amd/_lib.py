@@ -44,6 +44,7 @@ _SIGS = {
     "vbt_detect_async": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vbt_stream_create": (c_int, [c_int, c_void_p]),
     "vbt_stream_destroy": (c_int, [c_void_p]),
+    "vbt_streams_share_queue": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vbt_model_read_tensor": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "vbt_resize_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vbt_model_kernel_stats": (c_int, [c_void_p, c_int, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),

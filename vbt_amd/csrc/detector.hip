@@ -3284,6 +3284,26 @@ int vbt_stream_create(int device, void** stream_out) {
   *stream_out = (void*)st;
   return VBT_OK;
 }
+// Do two streams share a hardware queue?  A single-wave kernel that spins for `us` microseconds on each: side by side they
+// take `us`, on one in-order queue 2 x `us`.  (The queue of a stream cannot be queried; GPU otherwise idle when called.)
+__global__ void stream_spin_kernel(long ticks) {
+  const long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int vbt_streams_share_queue(void* a, void* b, int us, int* shared) {
+  if (!a || !b || !shared || us < 20 || us > 100000) { set_error("vbt_streams_share_queue: bad argument"); return VBT_ERR_ARG; }
+  const long ticks = (long)us * 100;   // wall_clock64: 100 MHz
+  VBT_HIP_CHECK(hipStreamSynchronize((hipStream_t)a));
+  VBT_HIP_CHECK(hipStreamSynchronize((hipStream_t)b));
+  auto t0 = std::chrono::steady_clock::now();
+  stream_spin_kernel<<<1, 64, 0, (hipStream_t)a>>>(ticks);
+  stream_spin_kernel<<<1, 64, 0, (hipStream_t)b>>>(ticks);
+  VBT_HIP_CHECK(hipStreamSynchronize((hipStream_t)a));
+  VBT_HIP_CHECK(hipStreamSynchronize((hipStream_t)b));
+  const double el = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  *shared = el > 1.6 * us ? 1 : 0;
+  return VBT_OK;
+}
 int vbt_stream_destroy(void* stream) {
   if (!stream) return VBT_OK;
   VBT_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));

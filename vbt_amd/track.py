@@ -127,6 +127,7 @@ class Pipeline:
         # been used before and then share a queue with a neighbour - measured 89 k -> 58 k frames/s.
         self._own_streams = []
         self._det_streams = [self._new_stream(tdev) for _ in range(self.depth)]
+        self._copy_stream = self._new_stream(tdev)
         self._trk_stream = self._new_stream(tdev)
         # Where the OC-SORT step of a frame runs.  "own": on the tracker stream (it waits for the slot's detections).  "inline":
         # at the end of the slot's own stream, after an event wait on the previous frame's tracker step.  The GPU runs four
@@ -138,6 +139,7 @@ class Pipeline:
         if mode not in ("own", "inline"):
             raise ValueError("VBT_TRACKER_STREAM must be 'own' or 'inline'")
         self._trk_inline = mode == "inline"
+        self._place_streams(tdev)
         self._last_trk_ev = None                    # the most recent tracker step (inline mode orders the steps through it)
         self._ev_in = [torch.cuda.Event() for _ in range(self.depth)]
         self._ev_det = [torch.cuda.Event() for _ in range(self.depth)]
@@ -149,7 +151,6 @@ class Pipeline:
         self._stage = [None] * (self.depth + 2)
         self._stage_free = [None] * (self.depth + 2)
         self._stage_idx = 0
-        self._copy_stream = self._new_stream(tdev)
         # Self-check: every slot runs its whole plan on a blank batch before the first real frame, so a plan the kernels
         # reject (LDS budget, tile shape) fails here and not in the middle of a clip; the first real step then also finds
         # code objects, arenas and GPU clocks warm.  Detector only: no tracker state is touched.
@@ -185,6 +186,45 @@ class Pipeline:
             i = len(pool["streams"]) - 1
         self._own_streams.append(i)
         return pool["streams"][i]
+
+    def _place_streams(self, tdev):
+        """The streams that carry kernels side by side (detector slots, the copy stream, the tracker stream unless its step
+        runs inline) must sit on distinct hardware queues.  HIP deals queues to streams in a zig-zag over GPU_MAX_HW_QUEUES
+        that also counts streams created by others (with 6 queues two detector streams of a fresh process shared one:
+        72 k instead of 94 k frames/s), and a stream's queue cannot be queried - so every pair is timed with a spinning wave
+        (vbt_streams_share_queue, 3 ms in all) and a stream that collides is swapped for the next one of the pool."""
+        if os.environ.get("VBT_TORCH_POOL_STREAMS") == "1" or os.environ.get("VBT_PLACE_STREAMS", "1") == "0":
+            return
+        import ctypes
+        L = _lib.lib()
+        self._torch.cuda.synchronize()
+
+        def shared(a, b):
+            sh = ctypes.c_int()
+            _lib.check(L.vbt_streams_share_queue(a.cuda_stream, b.cuda_stream, 150, ctypes.byref(sh)))
+            return bool(sh.value)
+
+        busy = [("det", k) for k in range(self.depth)] + [("copy", 0)] + ([] if self._trk_inline else [("trk", 0)])
+        placed, budget, warned = [], 12, False                # at most 12 replacement streams per pipeline
+        for kind, k in busy:
+            cur = self._det_streams[k] if kind == "det" else (self._copy_stream if kind == "copy" else self._trk_stream)
+            while any(shared(cur, p) for p in placed):
+                if budget == 0:
+                    if not warned:
+                        import warnings
+                        warnings.warn("vbt_amd: could not give every pipeline stream its own hardware queue (GPU_MAX_HW_QUEUES "
+                                      "too small, or kernels are being serialised by a profiler); throughput will be lower")
+                        warned = True
+                    break
+                budget -= 1
+                cur = self._new_stream(tdev)               # the colliding stream stays owned (out of the free list) until __del__
+            placed.append(cur)
+            if kind == "det":
+                self._det_streams[k] = cur
+            elif kind == "copy":
+                self._copy_stream = cur
+            else:
+                self._trk_stream = cur
 
     def __del__(self):
         try:
