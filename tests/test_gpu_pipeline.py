@@ -342,3 +342,24 @@ def test_tracker_on_the_detector_streams_gives_the_same_rows(model_path, monkeyp
         assert np.array_equal(a[i], b[i])
     assert int(a[1].sum()) > 10
     assert a[5] == b[5]
+
+
+def test_busy_streams_sit_on_distinct_hardware_queues(model_path):
+    """Pipeline._place_streams: after creation every pair of the streams that carry kernels side by side (detector slots +
+    the copy stream) runs two spinning waves concurrently; a stream against itself reads as shared (the probe's control)."""
+    import ctypes
+    from vbt_amd import _lib
+    from vbt_amd.track import Pipeline
+    pipe = Pipeline(model_path, 2, max_frames=4, fps=60.0)
+    L = _lib.lib()
+
+    def shared(a, b):
+        sh = ctypes.c_int()
+        _lib.check(L.vbt_streams_share_queue(a.cuda_stream, b.cuda_stream, 150, ctypes.byref(sh)))
+        return bool(sh.value)
+
+    busy = list(pipe._det_streams) + [pipe._copy_stream]
+    assert shared(busy[0], busy[0])
+    for i in range(len(busy)):
+        for j in range(i + 1, len(busy)):
+            assert not shared(busy[i], busy[j]), (i, j)
