@@ -12,10 +12,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --steps 20 --warmup 5 --cpu-frames 0 > $OUT/bench_k20.json 2> $OUT/bench_k20.err
-B="bench.py --steps 50 --warmup 5 --cpu-frames 0 --no-extras --no-roofline"
+B="bench.py --steps 50 --warmup 5 --cpu-frames 0 --no-extras --no-roofline --settle-steps 0"
 VBT_PIPELINE_DEPTH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d1 -o d1 -- python3 $B > /dev/null 2> $OUT/trace_d1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d3 -o d3 -- python3 $B > /dev/null 2> $OUT/trace_d3.err
-P="bench.py --steps 6 --warmup 2 --cpu-frames 0 --no-extras --no-roofline"
+P="bench.py --steps 6 --warmup 2 --cpu-frames 0 --no-extras --no-roofline --settle-steps 0"
 export VBT_PIPELINE_DEPTH=1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $P > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $P > /dev/null 2> $OUT/pmc_write.err
