@@ -181,7 +181,13 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 }
 
 // Several problems in one grid (the same head layer on all pyramid levels of both heads): the problem list lives in HBM.
-constexpr int BD_HEAD_WAVES = 8, BD_HEAD_MAXPX = 240;
+#ifndef VBT_BD_HEAD_WAVES
+#define VBT_BD_HEAD_WAVES 8
+#endif
+#ifndef VBT_BD_HEAD_MAXPX
+#define VBT_BD_HEAD_MAXPX 240
+#endif
+constexpr int BD_HEAD_WAVES = VBT_BD_HEAD_WAVES, BD_HEAD_MAXPX = VBT_BD_HEAD_MAXPX;
 __global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   int pi = 0;
