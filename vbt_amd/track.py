@@ -201,8 +201,11 @@ class Pipeline:
 
         def shared(a, b):
             sh = ctypes.c_int()
-            _lib.check(L.vbt_streams_share_queue(a.cuda_stream, b.cuda_stream, 150, ctypes.byref(sh)))
-            return bool(sh.value)
+            for _ in range(2):      # host-timed: a descheduled host thread can make one probe read "shared"; two in a row cannot
+                _lib.check(L.vbt_streams_share_queue(a.cuda_stream, b.cuda_stream, 150, ctypes.byref(sh)))
+                if not sh.value:
+                    return False
+            return True
 
         busy = [("det", k) for k in range(self.depth)] + [("copy", 0)] + ([] if self._trk_inline else [("trk", 0)])
         placed, budget, warned = [], 12, False                # at most 12 replacement streams per pipeline
