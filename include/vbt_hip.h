@@ -14,6 +14,7 @@
 #ifndef VBT_HIP_H
 #define VBT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -180,6 +181,33 @@ int vbt_tracker_update_from_detections(vbt_tracker* t, const float* boxes_dev, c
 int vbt_tracker_update_from_slots(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
                                   const int32_t* clip_of_slot_host, const double* times_host, int n_slots, float det_threshold,
                                   void* stream);
+
+/* Time-batched form.  The reference's unit of work is ONE video (track.py:85-126): `while cap.isOpened()` reads frame
+ * after frame of one clip (track.py:159-247).  The detector has no state, so a batch may hold RUNS of consecutive frames of
+ * a clip instead of one frame of each of B clips; the tracker then walks every run in frame order inside one launch (one
+ * wavefront per run).  Frame f (0-based) of a run sits in detector slot slot0 + f * slot_stride and is the reference's
+ * frame number frame_count = frame0 + f * frame_step (track.py:161; frame_step = the `frame_count % 16` stride of
+ * track.py:166, normally 1); its time stamp is frame_count / fps (track.py:169), one IEEE double division.  Frames on which
+ * run_odt returns [] do not step the tracker (track.py:180-181).  A clip may appear in at most one run per call; calls on
+ * one stream are ordered, so consecutive calls continue a clip.  runs_host is read during the call (kernel arguments). */
+typedef struct {
+  int32_t clip;         /* tracker clip the run belongs to (< 0: descriptor ignored) */
+  int32_t slot0;        /* detector slot of the run's first frame */
+  int32_t slot_stride;  /* 1: the run's frames are neighbours in the batch */
+  int32_t n_frames;     /* frames in the run */
+  int32_t frame0;       /* 1-based frame number of the first frame */
+  int32_t frame_step;   /* frame-number increment per frame of the run (>= 1) */
+  double fps;           /* cap.get(cv2.CAP_PROP_FPS), reference track.py:138 */
+} vbt_run;
+int vbt_tracker_update_from_detections_seq(vbt_tracker* t, const float* boxes_dev, const float* scores_dev,
+                                           const int32_t* counts_dev, int n_slots, const vbt_run* runs_host, int n_runs,
+                                           float det_threshold, void* stream);
+
+/* Assemble a detector batch from frames that live elsewhere in device memory (frame runs of different clips, or a clip
+ * whose frames are cycled): dst_dev[i] = *src_frames_host[i] for i < n_frames, frame_bytes each (a multiple of 16; all
+ * pointers 16-byte aligned).  src_frames_host is an array of DEVICE pointers held in host memory; it is read during the
+ * call (kernel arguments).  One launch per 64 frames, enqueued on `stream`. */
+int vbt_gather_frames(uint8_t* dst_dev, const uint8_t* const* src_frames_host, int n_frames, size_t frame_bytes, void* stream);
 
 /* What OCSort.update returned for the clip's most recent stepped frame: out7 [M,7] =
  * x1,y1,x2,y2,id(1-based),cls,score (reference track.py:190) and vel2 [M,2] = kf.x[4:6] of the

@@ -19,6 +19,12 @@ class TrackerParams(ctypes.Structure):
                 ("asso", ctypes.c_int32), ("iou_threshold", c_double), ("inertia", c_double), ("det_thresh", c_double)]
 
 
+class Run(ctypes.Structure):
+    """vbt_run (include/vbt_hip.h): a run of consecutive frames of one clip inside a detector batch."""
+    _fields_ = [("clip", ctypes.c_int32), ("slot0", ctypes.c_int32), ("slot_stride", ctypes.c_int32), ("n_frames", ctypes.c_int32),
+                ("frame0", ctypes.c_int32), ("frame_step", ctypes.c_int32), ("fps", c_double)]
+
+
 class KernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 32), ("launches", c_int), ("algorithmic_bytes", c_double), ("macs", c_double)]
 
@@ -63,6 +69,8 @@ _SIGS = {
     "vbt_tracker_finish": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p]),
     "vbt_tracker_phases": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_int32), c_void_p, c_int, ctypes.POINTER(c_int)]),
     "vbt_tracker_update_from_slots": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_float, c_void_p]),
+    "vbt_tracker_update_from_detections_seq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_float, c_void_p]),
+    "vbt_gather_frames": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_size_t, c_void_p]),
     "vbt_tracker_summary": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "vbt_tracker_rows_all": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vbt_analyze": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_void_p, c_int, ctypes.POINTER(c_int), c_int]),

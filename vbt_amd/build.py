@@ -2,39 +2,71 @@
 
 No torch.utils.cpp_extension, no JIT cache: the .so lives next to the package so that it travels
 to the GPU box with the snapshot (and is visible to the driver's "which .so was loaded" check).
+Every .hip translation unit is compiled to its own object (in parallel, only when it or a header
+changed) and the objects are linked into the one shared library.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libvbt_hip.so")
-SOURCES = ["detector.hip", "tracker.hip"]
-FLAGS = (["-DFB_MINW=" + os.environ["VBT_FB_MINW"]] if os.environ.get("VBT_FB_MINW") else []) + os.environ.get("VBT_EXTRA_CXXFLAGS", "").split() + ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = (["-DFB_MINW=" + os.environ["VBT_FB_MINW"]] if os.environ.get("VBT_FB_MINW") else []) + os.environ.get("VBT_EXTRA_CXXFLAGS", "").split() + ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
          # MFMA results land in VGPRs (gfx90a+ unified register file): the requantisation epilogues read the
          # accumulators directly instead of through one v_accvgpr_read per element
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+           [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include")) if f.endswith(".h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vbt_hip.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def needs_build():
+    return _stale(LIB, [os.path.join(CSRC, s) for s in sources()] + _headers())
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    flag_tag = os.path.join(OBJ, "flags.txt")                    # objects built with other flags are stale too
+    flags_txt = " ".join(FLAGS)
+    if not os.path.exists(flag_tag) or open(flag_tag).read() != flags_txt:
+        force = True
+    jobs = []
+    for s in sources():
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", "-o", obj, src])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), int(os.environ.get("VBT_BUILD_JOBS", "6"))))) as ex:
+        list(ex.map(run, jobs))
+    with open(flag_tag, "w") as f:
+        f.write(flags_txt)
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [os.path.join(OBJ, s[:-4] + ".o") for s in sources()])
     return LIB
 
 

@@ -647,6 +647,26 @@ struct StepMeta {
   double time[META_SLOTS];
   int clip[META_SLOTS];
 };
+// One detector slot -> the tracker's detection list, lane i = detection i (the slot's 25 scores / boxes arrive in one
+// round trip instead of 25 dependent ones by lane 0): threshold of reference odt.py:70-75 (score >= det_threshold), the
+// reorder of odt.py:102-118 and OC-SORT's own gate (score > det_thresh), order kept.  Returns the number of detections
+// handed to the tracker, or -1 when run_odt would have returned [] (the frame is skipped, track.py:180-181).  Uniform.
+__device__ inline int load_slot_detections(StepShared& sh, const float* boxes, const float* scores, const int* counts, int slot,
+                                           float det_threshold, double det_thresh, int lane) {
+  const int n = min(counts[slot], MAXD);
+  const float s = lane < n ? scores[slot * MAXD + lane] : 0.0f;
+  const bool kept = lane < n && s >= det_threshold;
+  const bool used = kept && (double)s > det_thresh;
+  const unsigned long long mk = __ballot(kept), mu = __ballot(used);
+  if (used) {
+    const int m = __popcll(mu & ((1ull << lane) - 1ull));
+    const float4 b = *(const float4*)(boxes + ((size_t)slot * MAXD + lane) * 4);  // ymin,xmin,ymax,xmax
+    sh.det[m][0] = (double)b.y; sh.det[m][1] = (double)b.x; sh.det[m][2] = (double)b.w; sh.det[m][3] = (double)b.z;
+    sh.det[m][4] = (double)s; sh.det[m][5] = 0.0;
+  }
+  return mk ? __popcll(mu) : -1;
+}
+
 __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states, Row* rows, int rows_cap, const float* boxes,
                                                               const float* scores, const int* counts, StepMeta meta, int slot0,
                                                               float det_threshold, TrackParams p, double q44, double q66) {
@@ -656,25 +676,42 @@ __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states,
   const double frame_time = meta.time[blockIdx.x];
   if (clip < 0 || !(frame_time >= 0.0)) return;
   ClipState& st = states[clip];
-  if (lane == 0) {
-    int n = counts[slot], m = 0, mk = 0;
-    for (int i = 0; i < n && i < MAXD; i++) {
-      float s = scores[slot * MAXD + i];
-      if (s >= det_threshold) {
-        mk++;
-        if ((double)s > p.det_thresh) {
-          const float* b = boxes + ((size_t)slot * MAXD + i) * 4;  // ymin,xmin,ymax,xmax
-          sh.det[m][0] = (double)b[1]; sh.det[m][1] = (double)b[0]; sh.det[m][2] = (double)b[3]; sh.det[m][3] = (double)b[2];
-          sh.det[m][4] = (double)s; sh.det[m][5] = 0.0;
-          m++;
-        }
-      }
-    }
-    sh.flag = mk > 0 ? m : -1;
-  }
+  const int nd = load_slot_detections(sh, boxes, scores, counts, slot, det_threshold, p.det_thresh, lane);
   __syncthreads();
-  if (sh.flag < 0) return;
-  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, sh.flag, frame_time, p, q44, q66, lane);
+  if (nd < 0) return;
+  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, nd, frame_time, p, q44, q66, lane);
+}
+
+// Time-batched form (the reference's unit of work is ONE video, track.py:85-126,159-247): the detector batch holds RUNS of
+// consecutive frames of a clip instead of one frame of each of B clips - the detector is stateless, so a single clip fills
+// the whole batch.  One wavefront per run walks its frames in order (frame f of the run sits in detector slot
+// slot0 + f * slot_stride); the frame time is frame_count / fps (track.py:161,169) with frame_count = frame0 + f * frame_step,
+// one IEEE division like the reference's.  Run descriptors travel in the kernel arguments (64 runs per launch).
+constexpr int META_RUNS = 64;
+struct RunMeta {
+  int clip, slot0, slot_stride, n_frames, frame0, frame_step;
+  double fps;
+};
+struct SeqMeta {
+  RunMeta run[META_RUNS];
+};
+__global__ __launch_bounds__(64) void tracker_seq_kernel(ClipState* states, Row* rows, int rows_cap, const float* boxes,
+                                                         const float* scores, const int* counts, SeqMeta meta,
+                                                         float det_threshold, TrackParams p, double q44, double q66) {
+  __shared__ StepShared sh;
+  const int lane = threadIdx.x;
+  const RunMeta r = meta.run[blockIdx.x];
+  if (r.clip < 0) return;
+  ClipState& st = states[r.clip];
+  Row* myrows = rows + (size_t)r.clip * rows_cap;
+  for (int f = 0; f < r.n_frames; f++) {
+    __syncthreads();  // the previous frame's readers of sh.det are done
+    const int nd = load_slot_detections(sh, boxes, scores, counts, r.slot0 + f * r.slot_stride, det_threshold, p.det_thresh, lane);
+    __syncthreads();
+    if (nd < 0) continue;
+    const double frame_time = (double)(r.frame0 + f * r.frame_step) / r.fps;
+    ocsort_step(st, myrows, rows_cap, sh, nd, frame_time, p, q44, q66, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1029,6 +1066,7 @@ int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts
 // One tracker step for slots [0, n_slots): launches of at most META_SLOTS workgroups, metadata in the kernel arguments.
 static int launch_steps(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev, const int32_t* clip_of_slot,
                         const double* times, int n_slots, float det_threshold, hipStream_t st) {
+  if (((uintptr_t)boxes_dev & 15) != 0) { set_error("tracker update: boxes_dev must be 16-byte aligned"); return VBT_ERR_ARG; }
   for (int s0 = 0; s0 < n_slots; s0 += META_SLOTS) {
     const int nb = std::min(META_SLOTS, n_slots - s0);
     StepMeta meta;
@@ -1063,6 +1101,45 @@ int vbt_tracker_update_from_slots(vbt_tracker* t, const float* boxes_dev, const 
       if (clip_of_slot_host[i] >= 0 && clip_of_slot_host[i] == clip_of_slot_host[j]) { set_error("clip %d sits in two slots", clip_of_slot_host[i]); return VBT_ERR_ARG; }
   }
   return launch_steps(t, boxes_dev, scores_dev, counts_dev, clip_of_slot_host, times_host, n_slots, det_threshold, (hipStream_t)stream);
+}
+
+int vbt_tracker_update_from_detections_seq(vbt_tracker* t, const float* boxes_dev, const float* scores_dev, const int32_t* counts_dev,
+                                           int n_slots, const vbt_run* runs_host, int n_runs, float det_threshold, void* stream) {
+  if (!t || !boxes_dev || !scores_dev || !counts_dev || !runs_host || n_runs < 1 || n_slots < 1) {
+    set_error("vbt_tracker_update_from_detections_seq: bad argument");
+    return VBT_ERR_ARG;
+  }
+  if (((uintptr_t)boxes_dev & 15) != 0) { set_error("vbt_tracker_update_from_detections_seq: boxes_dev must be 16-byte aligned"); return VBT_ERR_ARG; }
+  // every run stays inside the detector batch and no clip appears twice (two wavefronts would step one Kalman state)
+  std::vector<char> seen((size_t)t->n_clips, 0);
+  for (int i = 0; i < n_runs; i++) {
+    const vbt_run& r = runs_host[i];
+    if (r.clip < 0) continue;  // an empty descriptor
+    if (r.clip >= t->n_clips) { set_error("run %d: clip %d, tracker has %d clips", i, r.clip, t->n_clips); return VBT_ERR_ARG; }
+    if (seen[r.clip]) { set_error("run %d: clip %d appears in two runs of one call", i, r.clip); return VBT_ERR_ARG; }
+    seen[r.clip] = 1;
+    if (r.n_frames < 1 || r.frame0 < 1 || r.frame_step < 1 || !(r.fps > 0.0)) { set_error("run %d: n_frames, frame0, frame_step >= 1 and fps > 0 required", i); return VBT_ERR_ARG; }
+    const long long last = (long long)r.slot0 + (long long)(r.n_frames - 1) * r.slot_stride;
+    if (r.slot0 < 0 || r.slot0 >= n_slots || last < 0 || last >= n_slots) {
+      set_error("run %d: slots %d..%lld outside the detector batch of %d", i, r.slot0, last, n_slots);
+      return VBT_ERR_ARG;
+    }
+    if ((long long)r.frame0 + (long long)(r.n_frames - 1) * r.frame_step > 0x7fffffffLL) { set_error("run %d: frame number overflow", i); return VBT_ERR_ARG; }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int r0 = 0; r0 < n_runs; r0 += META_RUNS) {
+    const int nb = std::min(META_RUNS, n_runs - r0);
+    SeqMeta meta;
+    for (int i = 0; i < nb; i++) {
+      const vbt_run& r = runs_host[r0 + i];
+      meta.run[i] = RunMeta{r.clip, r.slot0, r.slot_stride, r.n_frames, r.frame0, r.frame_step, r.fps};
+    }
+    tracker_seq_kernel<<<nb, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, meta, det_threshold, t->p, t->q44,
+                                          t->q66);
+  }
+  VBT_HIP_CHECK(hipGetLastError());
+  t->finished = false;
+  return VBT_OK;
 }
 
 static int fetch_state_header(vbt_tracker* t, int clip, ClipState* hdr_only) {

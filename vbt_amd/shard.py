@@ -35,6 +35,48 @@ def slot_schedule(lengths, n_slots):
     return cmap, fidx
 
 
+def run_schedule(lengths, n_slots, max_run=None):
+    """Time-batched schedule of clips of `lengths[c]` frames through a detector batch of `n_slots` frames per step: every
+    step hands each unfinished clip a RUN of consecutive frames, the slots being dealt in proportion to the frames the clips
+    have left (largest remainders first, ties to the lower clip), so that every slot of every step but the last carries a
+    frame and all clips end together - the sequential OC-SORT walk of a step is then as short as it can be
+    (max run = ceil(n_slots * longest / total)).  max_run caps the frames of one clip per step.
+    Returns a list of steps; a step is a list of (clip, slot0, n_frames, frame0) with frame0 1-based."""
+    left = np.asarray(lengths, np.int64).copy()
+    done = np.zeros_like(left)
+    steps = []
+    while left.sum() > 0:
+        total = int(left.sum())
+        if total <= n_slots and (max_run is None or left.max() <= max_run):
+            give = left.copy()
+        else:
+            quota = left * (n_slots / total)
+            give = np.minimum(np.floor(quota).astype(np.int64), left)
+            if max_run is not None:
+                give = np.minimum(give, max_run)
+            spare = n_slots - int(give.sum())
+            cap = left if max_run is None else np.minimum(left, max_run)
+            order = sorted(range(len(left)), key=lambda c: (-(quota[c] - np.floor(quota[c])), c))
+            while spare > 0:
+                moved = False
+                for c in order:
+                    if spare > 0 and give[c] < cap[c]:
+                        give[c] += 1
+                        spare -= 1
+                        moved = True
+                if not moved:
+                    break
+        step, slot = [], 0
+        for c in range(len(left)):
+            if give[c] > 0:
+                step.append((c, slot, int(give[c]), int(done[c]) + 1))
+                slot += int(give[c])
+        done += give
+        left -= give
+        steps.append(step)
+    return steps
+
+
 def gather_records(rec, dist, pad_to):
     """rec: tensor [n_i, k] of this rank's records (n_i <= pad_to).  Returns the valid rows of all ranks
     (numpy) on every rank via ONE all_gather of equal-size blocks (row 0 of each block carries n_i)."""

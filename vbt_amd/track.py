@@ -249,7 +249,11 @@ class Pipeline:
         # frame times / clip map of the step travel in the kernel arguments (read during the call, no copy in flight)
         tm = self._times[k]
         mp = self._maps[k]
-        if mp is not None:
+        if isinstance(mp, tuple):                                    # time-batched step: runs of consecutive frames
+            _, ra, B = mp
+            _lib.check(_lib.lib().vbt_tracker_update_from_detections_seq(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(), B,
+                                                                         ra, len(ra), self.thr, T.cuda_stream))
+        elif mp is not None:
             _lib.check(_lib.lib().vbt_tracker_update_from_slots(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(),
                                                                 mp.ctypes.data, tm.ctypes.data, self.n, self.thr, T.cuda_stream))
         else:
@@ -299,8 +303,7 @@ class Pipeline:
         if host_frames is not None:
             stage_j = j = self._stage_idx % len(self._stage)
             self._stage_idx += 1
-            if self._stage[j] is None or self._stage[j].shape != host_frames.shape:
-                self._stage[j] = torch.empty(host_frames.shape, dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
+            self._staging(j, host_frames.shape)
             C = self._copy_stream
             C.wait_event(self._ev_in[k])
             if self._stage_free[j] is not None:
@@ -347,6 +350,135 @@ class Pipeline:
         while len(self._pending) >= (1 if self._trk_inline else self.depth):
             self._enqueue_tracker(self._pending.pop(0))
 
+    def _staging(self, j, shape):
+        """Staging buffer j of the host-fed / gathered input ring with (at least) the given shape.  A buffer that has to be
+        replaced may still be read by a forward or written by a copy in flight (up to depth + 2 steps): it is handed back
+        to the caching allocator only after every stream of the pipeline has been told about it."""
+        torch = self._torch
+        cur = self._stage[j]
+        if cur is None or tuple(cur.shape) != tuple(shape):
+            if cur is not None:
+                for S in self._det_streams + [self._copy_stream]:
+                    cur.record_stream(S)
+            self._stage[j] = torch.empty(tuple(shape), dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
+        return self._stage[j]
+
+    def step_runs(self, frames, runs, stream=None, src_hw=None, swap_rb=False, track=True):
+        """Time-batched step (the reference's unit of work is ONE video, track.py:85-126,159-247): the detector batch holds
+        RUNS of consecutive frames of a clip instead of one frame of each clip; the OC-SORT steps of a run are walked in
+        frame order by one wavefront inside ONE tracker launch (vbt_tracker_update_from_detections_seq).
+        runs: sequence of (clip, slot0, n_frames, frame0[, frame_step]) - frame f of the run sits in batch slot slot0 + f and
+        is frame number frame0 + f * frame_step (1-based) of tracker clip `clip`; its time stamp is frame number / fps[clip].
+        frames: the assembled batch - a device tensor / raw device pointer or a (pinned) host tensor [B,H,W,3], B = slots used
+        - or a list with one tensor [n_frames,H,W,3] per run (device or host, contiguous): the batch is then assembled here,
+        by one gather launch (device sources) or one H2D copy per run on the copy stream (host sources)."""
+        torch = self._torch
+        L = _lib.lib()
+        k = self._step_idx % self.depth
+        if k in self._pending:
+            raise RuntimeError(f"Pipeline: ring slot {k} still holds a step whose tracker update has not been enqueued")
+        ra = (_lib.Run * len(runs))()
+        B = 0
+        for i, r in enumerate(runs):
+            clip, slot0, nf, frame0 = (int(v) for v in r[:4])
+            fstep = int(r[4]) if len(r) > 4 else 1
+            if not (0 <= clip < self.n_trk) or nf < 1 or slot0 < 0 or slot0 + nf > self.n:
+                raise ValueError(f"run {i}: clip {clip}, slots {slot0}..{slot0 + nf - 1} outside {self.n_trk} clips / {self.n} slots")
+            ra[i] = _lib.Run(clip, slot0, 1, nf, frame0, fstep, float(self.fps[clip]))
+            B = max(B, slot0 + nf)
+        self._step_idx += 1
+        S = self._det_streams[k]
+        self._ev_in[k].record(torch.cuda.current_stream())
+        S.wait_event(self._ev_in[k])
+        if self._ev_trk[k] is not None:
+            S.wait_event(self._ev_trk[k])
+        size = int(self.interpreter.get_input_details()[0]["shape"][1])
+        stage_j = None
+        if isinstance(frames, (list, tuple)):
+            if len(frames) != len(runs):
+                raise ValueError("one source tensor per run")
+            shp = tuple(frames[0].shape[1:])
+            stage_j = j = self._stage_idx % len(self._stage)
+            self._stage_idx += 1
+            st = self._staging(j, (self.n,) + shp)
+            fb = int(np.prod(shp))
+            on_host = frames[0].device.type == "cpu"
+            if on_host:
+                C = self._copy_stream
+                C.wait_event(self._ev_in[k])
+                if self._stage_free[j] is not None:
+                    C.wait_event(self._stage_free[j])
+                with torch.cuda.stream(C):
+                    for src, r in zip(frames, ra):
+                        st[r.slot0:r.slot0 + r.n_frames].copy_(src[:r.n_frames], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(C)
+                S.wait_event(ev)
+            else:
+                if self._stage_free[j] is not None:
+                    S.wait_event(self._stage_free[j])
+                ptrs = (ctypes.c_void_p * B)()
+                for src, r in zip(frames, ra):
+                    src.record_stream(S)
+                    base = src.data_ptr()
+                    for f in range(r.n_frames):
+                        ptrs[r.slot0 + f] = base + f * fb
+                if any(not p for p in ptrs):
+                    raise ValueError("step_runs: the runs leave a hole in the detector batch")
+                _lib.check(L.vbt_gather_frames(st.data_ptr(), ptrs, B, fb, S.cuda_stream))
+            frames_ptr = st.data_ptr()
+        elif hasattr(frames, "data_ptr"):
+            if frames.device.type == "cpu":
+                stage_j = j = self._stage_idx % len(self._stage)
+                self._stage_idx += 1
+                st = self._staging(j, (self.n,) + tuple(frames.shape[1:]))
+                C = self._copy_stream
+                C.wait_event(self._ev_in[k])
+                if self._stage_free[j] is not None:
+                    C.wait_event(self._stage_free[j])
+                with torch.cuda.stream(C):
+                    st[:frames.shape[0]].copy_(frames, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(C)
+                S.wait_event(ev)
+                frames_ptr = st.data_ptr()
+            else:
+                frames.record_stream(S)
+                frames_ptr = frames.data_ptr()
+        else:
+            frames_ptr = frames
+        if src_hw is not None and (tuple(src_hw) != (size, size) or swap_rb):
+            if self._resized[k] is None:
+                self._resized[k] = torch.empty((self.n, size, size, 3), dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
+            _lib.check(L.vbt_resize_frames(frames_ptr, B, int(src_hw[0]), int(src_hw[1]), 1, self._resized[k].data_ptr(), size, size, 1,
+                                           int(bool(swap_rb)), self._dev, S.cuda_stream))
+            frames_ptr = self._resized[k].data_ptr()
+        b, s_, c, cnt = self._bufs[k]
+        _lib.check(L.vbt_detect_async(self.interpreters[k].handle, frames_ptr, B, S.cuda_stream, b.data_ptr(), s_.data_ptr(), c.data_ptr(),
+                                      cnt.data_ptr()))
+        self._ev_det[k].record(S)
+        if stage_j is not None:
+            ev = torch.cuda.Event()
+            ev.record(S)
+            self._stage_free[stage_j] = ev
+        self._maps[k] = ("runs", ra, B)
+        self._last_B = B
+        if not track:
+            return
+        self._pending.append(k)
+        while len(self._pending) >= (1 if self._trk_inline else self.depth):
+            self._enqueue_tracker(self._pending.pop(0))
+
+    def step_seq(self, frames, frame0=None, stream=None, **kw):
+        """F consecutive frames of EVERY clip in one step: frames [n_clips, F, H, W, 3] (clip-major, device or pinned host
+        tensor); the clips' frame counters advance by F."""
+        ncl, F = int(frames.shape[0]), int(frames.shape[1])
+        if ncl != self.n_trk or ncl * F > self.n:
+            raise ValueError(f"step_seq: {ncl} clips x {F} frames do not fit {self.n_trk} clips / {self.n} slots")
+        f0 = self.frame_count + 1 if frame0 is None else int(frame0)
+        self.step_runs(frames.reshape((ncl * F,) + tuple(frames.shape[2:])), [(c, c * F, F, f0) for c in range(ncl)], stream, **kw)
+        self.frame_count = f0 + F - 1
+
     def reset(self):
         """Back to frame 0 of fresh clips (tracker state cleared); models, streams and buffers are kept."""
         self._drain()
@@ -361,6 +493,8 @@ class Pipeline:
 
     def tracker_only_steps(self, count, slot=0):
         """Measurement split: `count` tracker steps of all clips on the detections sitting in ring slot `slot`."""
+        if self.n_trk != self.n:
+            raise RuntimeError("tracker_only_steps needs one tracker clip per detector slot")
         b, s, c, cnt = self._bufs[slot]
         T = self._trk_stream
         T.wait_event(self._ev_det[slot])
