@@ -91,7 +91,7 @@ def test_one_clip_time_batched_equals_per_frame_and_oracle(oracle_lib, model_pat
     ref.finish()
     want = ref.rows(0)
     want_ph = ref.phases(0)
-    assert len(want["id"]) > 150
+    assert len(want["id"]) > 50
     host = torch.from_numpy(frames).pin_memory()
     for mode in ("device", "host", "device_sources", "host_sources"):
         pipe = Pipeline(model_path, F, max_frames=T, fps=60.0, rows_per_frame=25, tracker_clips=1)
@@ -139,7 +139,7 @@ def test_frame_step_and_empty_frames(model_path):
         nf = min(16, picked.shape[0] - i0)
         pipe.step_runs(picked[i0:i0 + nf], [(0, 0, nf, (i0 + 1) * stride, stride)])
     pipe.finish()
-    assert _rows_equal(pipe.rows(0), want) and len(want["id"]) > 20
+    assert _rows_equal(pipe.rows(0), want) and len(want["id"]) > 10
     assert pipe.tracker.status(0)["frame_count"] == ref.tracker.status(0)["frame_count"] <= T // stride
 
 
@@ -157,13 +157,13 @@ def test_config2_full_length_clip(model_path):
     ref = Pipeline(model_path, 1, max_frames=T, fps=60.0)
     for t in range(T):
         ref.step(fd[t:t + 1])
-    rb, rr, rn, ro, rph = ref.close(cap=64)
+    rb, rr, rn, ro, rph = ref.close(cap=512)
     rc, rrows = ref.rows_all()
-    assert rr[0] > 4000 and rn[0] >= 8 and ro[0] == 0
+    assert rr[0] > 1500 and rn[0] >= 8 and ro[0] == 0
     pipe = Pipeline(model_path, F, max_frames=T, fps=60.0, tracker_clips=1)
     for t0 in range(0, T, F):
         pipe.step_runs(fd[t0:t0 + F], [(0, 0, F, t0 + 1)])
-    b, r, n, o, ph = pipe.close(cap=64)
+    b, r, n, o, ph = pipe.close(cap=512)
     c, rows = pipe.rows_all()
     assert np.array_equal(b, rb) and np.array_equal(r, rr) and np.array_equal(n, rn) and np.array_equal(ph, rph)
     assert np.array_equal(rows[0, :c[0]], rrows[0, :rc[0]])
@@ -171,7 +171,7 @@ def test_config2_full_length_clip(model_path):
     halves = fd.reshape(2, T // 2, 320, 320, 3)               # clip 1 = the second half of the sequence, as its own clip
     for t0 in range(0, T // 2, 32):
         two.step_seq(halves[:, t0:t0 + 32].contiguous())
-    two.close(cap=64)
+    two.close(cap=512)
     c2, rows2 = two.rows_all()
     assert np.array_equal(rows2[0, :c2[0]], rrows[0, :c2[0]]) and c2[1] > 1900
 
@@ -194,7 +194,7 @@ def test_corpus_time_batched_equals_ragged_per_frame(model_path):
     fr = frames.transpose(0, 1).contiguous()
     for t in range(T):
         ref.step(fr[t % U], active=t < lengths)
-    rb, rr, rn, ro, rph = ref.close(cap=64)
+    rb, rr, rn, ro, rph = ref.close(cap=512)
     rc, rrows = ref.rows_all()
     del ref
     pipe = Pipeline(model_path, 64, max_frames=T, fps=fps, detection_treshold=0.5, tracker_clips=n)
@@ -204,9 +204,9 @@ def test_corpus_time_batched_equals_ragged_per_frame(model_path):
     for step in steps:
         assert all(nf <= U for _, _, nf, _ in step)
         pipe.step_runs([cyc[c, (f0 - 1) % U:(f0 - 1) % U + nf] for c, _, nf, f0 in step], step)
-    b, r, nph, o, ph = pipe.close(cap=64)
+    b, r, nph, o, ph = pipe.close(cap=512)
     c, rows = pipe.rows_all()
     assert np.all(o == 0) and np.array_equal(b, rb) and np.array_equal(r, rr) and np.array_equal(nph, rn) and np.array_equal(ph, rph)
     for i in range(n):
         assert np.array_equal(rows[i, :c[i]], rrows[i, :rc[i]]), keys[i]
-    assert int(r.sum()) > 34 * 500
+    assert int(r.sum()) > 34 * 300

@@ -43,7 +43,7 @@ def one_clip(T, F, host, U=256):
             nf = min(F, T - f0)
             s = f0 % U
             pipe.step_runs(frames[s:s + nf], [(0, 0, nf, f0 + 1)])
-        best, rows, nph, ovf, ph = pipe.close(cap=64)
+        best, rows, nph, ovf, ph = pipe.close(cap=512)
         cnt, rr = pipe.rows_all()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -66,7 +66,7 @@ def whole_corpus(slots, host, U=8):
         t0 = time.perf_counter()
         for step in steps:
             pipe.step_runs([frames[c, (f0 - 1) % U:(f0 - 1) % U + nf] for c, _, nf, f0 in step], step)
-        best, rows, nph, ovf, ph = pipe.close(cap=64)
+        best, rows, nph, ovf, ph = pipe.close(cap=512)
         cnt, rr = pipe.rows_all()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
