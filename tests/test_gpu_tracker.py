@@ -187,3 +187,38 @@ def test_finish_selects_id_and_phases_for_reference_clip():
     # the replay lacks the ~20 observations the reference's min_hits rule hid after lost periods, so the ACVs
     # sit within 2e-3 m/s of the SURVEY 4.3 table rather than on it
     assert np.allclose(acv, [0.437798, 0.481084, 0.455869, 0.445342, 0.391556, 0.400236], atol=2e-3)
+
+
+def test_whole_reference_corpus_replayed_on_the_device():
+    """All 34 reference DataFrames (every id) replayed through the HIP tracker in ONE launch, one wavefront per clip:
+    the row log equals the numpy oracle's bit for bit on every clip, and on the 22 single-track clips it IS the reference
+    DataFrame (ids, emission order, time/x/y/dx/dy bit for bit) - see tests/test_oracle_ocsort_corpus.py for what the
+    other 12 clips can and cannot pin."""
+    from oracle import ocsort_np as oc
+    from test_oracle_ocsort import frames_from_rows
+    from test_oracle_ocsort_corpus import load_all, single_track_clips
+    from vbt_amd.ocsort import MultiClipTracker
+    corpus = load_all()
+    clips = sorted(corpus)
+    data = [frames_from_rows(corpus[c][0]) for c in clips]
+    dets, counts, times = _pack([d[0] for d in data], [d[1] for d in data])
+    mc = MultiClipTracker(len(clips), 8192, max_age=30, asso_func="diou", iou_threshold=0.1)
+    mc.update_frames(dets, counts, times)
+    clean = set(single_track_clips(corpus))
+    assert len(clean) == 22
+    for ci, clip in enumerate(clips):
+        got = {k: np.asarray(v) for k, v in mc.rows(ci).items()}
+        want = {k: np.asarray(v) for k, v in oc.track_boxes(*data[ci]).items()}
+        assert mc.status(ci)["overflow"] == 0 and mc.status(ci)["rows_overflow"] == 0
+        for k in ["id"] + COLS:
+            assert np.array_equal(got[k], want[k]), (clip, k)
+        if clip in clean:
+            g = corpus[clip][0]
+            order = np.argsort(g["index"])
+            assert np.array_equal(got["id"], g["id"][order])
+            for k in ("time", "x", "y", "dx", "dy"):
+                assert np.array_equal(got[k], g[k][order]), (clip, k)
+    # export id (reference track.py:107-115: the file name carries it) of every clip, selected on the device
+    mc.finish(0.45)
+    for ci, clip in enumerate(clips):
+        assert mc.phases(ci)[0] == corpus[clip][1], clip
