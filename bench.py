@@ -3,7 +3,7 @@
 
 One STEP = one pass of the hot path over one batch: frame t of each of `--clips` (default 64)
 synthetic clips per GPU -> int8 EfficientDet-Lite0 -> decode + NMS -> one OC-SORT step per clip,
-all enqueued on one HIP stream with the frames already resident in HBM.  After the K timed steps
+all enqueued on HIP streams with the frames already resident in HBM.  After the K timed steps
 the clips are closed inside the timed region too: export-id selection + preprocessing +
 VelocityTracker on the device, then (N > 1) one RCCL all-gather of the per-clip result records.
 
@@ -11,15 +11,26 @@ VelocityTracker on the device, then (N > 1) one RCCL all-gather of the per-clip 
   (N > 1: launched by torch.distributed.run, one rank per GPU; ranks own disjoint clips, no
    data-path collective -> "weak" scaling; the only exchange is the final result gather.)
 
-Prints ONE JSON line on rank 0 (see the keys at the bottom).  `roofline` is for the dominant kernel
-family, timed with HIP events on the launch stream in a separate pass of the same process;
-`cpu_baseline` times the CPU oracle (a port: the reference's TFLite path cannot run here) on a
-bounded sample of the same workload on rank 0 at N = 1.
+Prints ONE JSON line on rank 0.  Which number is which:
+  value                 the contract: W warm-up steps, then exactly K steps + clip close between two fences, frames resident
+                        in HBM (what the task's bench contract defines as `value`).
+  value_h2d_inclusive   SURVEY.md 8d's metric, measured with the SAME W and K in the same process: uint8 frames in pinned
+                        host memory -> H2D -> detect + NMS + track -> clip close -> every DataFrame row back in pinned host
+                        memory, all inside its timed region.
+  cold_start            the contract run repeated in a FRESH process that starts before this one touches the GPU, without
+                        the clock-settle phase: what the first GPU process on an idle MI355X measures.
+  configs               BASELINE.json's other configurations (batch 1, batch 8, one clip time-batched, the 34-clip corpus on
+                        one GPU, Lite2 448x448), each with its SURVEY 8d roofline fraction.
+  roofline              dominant kernel family, timed as ONE HIP-event bracket around all of its launches (the way
+                        rocprofv3 --kernel-trace sees them; profiles/), with the PMC traffic of the same plan beside it.
+  cpu_baseline          the CPU oracle (a port: the reference's TFLite path cannot run here) on a bounded sample.
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,12 +41,28 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # before torch initialises HIP (see vbt_amd/__init__.py)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
-# The kernel plan tuned on an MI355X at B = 64 is pinned so that every run (and the committed rocprofv3 / PMC
-# summaries under profiles/) executes the same kernels; a different batch size or missing file re-tunes.
-os.environ.setdefault("VBT_PLAN_FILE", os.path.join(ROOT, "profiles", "plan_lite0"))
-COUNTERS_JSON = os.path.join(ROOT, "profiles", "r02_counters.json")
-# VBT_BENCH_MODEL: rehearsal knob (e.g. a Lite2 container for BASELINE config 4); the contract line is always Lite0
+# Kernel plans tuned on an MI355X are pinned (profiles/plan_<model>.b<batch>.f0) so that every run and the committed
+# rocprofv3 / PMC summaries under profiles/ execute the same kernels; a missing file re-tunes on the spot.
+PLAN_LITE0 = os.path.join(ROOT, "profiles", "plan_lite0")
+PLAN_LITE2 = os.path.join(ROOT, "profiles", "plan_lite2")
+os.environ.setdefault("VBT_PLAN_FILE", PLAN_LITE0)
+COUNTERS = [os.path.join(ROOT, "profiles", f) for f in ("r03_counters.json", "r02_counters.json")]
+# VBT_BENCH_MODEL: rehearsal knob; the contract line is always Lite0
 MODEL = os.environ.get("VBT_BENCH_MODEL", os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm"))
+MODEL_LITE2 = os.path.join(ROOT, "models", "efficientdet_lite2_synth.vbtm")
+CORPUS_META = os.path.join(ROOT, "tests", "golden", "corpus_meta.json")   # real frame counts / fps of the reference's 34 clips
+# algorithmic bytes per frame = activation elements (each op reads its inputs and writes its output once) +
+# weight elements / batch, at the 1 byte per element of the full-integer graph
+ALG_ELEMS = {0: (36.84e6, 3.27e6), 2: (115.56e6, 5.44e6)}
+
+
+def alg_bytes_per_frame(arch, batch):
+    a, w = ALG_ELEMS[arch]
+    return a + w / batch
+
+
+def roofline_frac_8d(frames_per_s, arch, batch):
+    return frames_per_s * alg_bytes_per_frame(arch, batch) / HBM_PEAK
 
 
 def make_frames(clip_seeds, t0, n_steps, size=320):
@@ -49,6 +76,9 @@ def make_frames(clip_seeds, t0, n_steps, size=320):
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------------------------
 def cpu_leg(n_frames, threads):
     """Oracle (CPU port) on a bounded sample: detector for n_frames frames (OpenMP over frames),
     then OC-SORT + rep analysis in numpy/python over the detections, as 8 clips."""
@@ -129,9 +159,14 @@ def _cpu_name():
     return "unknown"
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# process plumbing
+# ----------------------------------------------------------------------------------------------------------------
 def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes (one per GPU, RCCL rendezvous on 127.0.0.1),
+    started BEFORE this process makes any GPU call.  A rank that dies takes the others down (torch.distributed.run) and its
+    exit code comes back; a rendezvous that never completes is bounded by VBT_BENCH_TIMEOUT_S in every rank."""
     import socket
-    import subprocess
     with socket.socket() as sk:                      # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -143,6 +178,20 @@ def self_launch(n):
     return proc.returncode
 
 
+def cold_start_child(args):
+    """The contract run in a fresh process, before this one has touched the GPU, without the clock-settle phase."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--clips", str(args.clips),
+           "--settle-steps", "0", "--contract-only"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+        j = json.loads(line)
+        return {"value": j["value"], "ms_per_step": j["ms_per_step"], "settle_steps": 0,
+                "note": "fresh process started before the parent touched the GPU; same --steps / --warmup, no clock-settle phase"}
+    except Exception as e:   # the headline must not die with the diagnostic
+        return {"value": None, "error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,23 +201,28 @@ def main():
     ap.add_argument("--unique-steps", type=int, default=64, help="distinct frame sets kept in HBM and cycled")
     ap.add_argument("--cpu-frames", type=int, default=2048, help="frames of the all-cores CPU baseline leg (the 4-thread leg takes a quarter); about 25 s of CPU work in all (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive pass and the detect-only / track-only splits")
+    ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive pass, the splits and the other configurations")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's other configurations (b1, b8, clip1, corpus, Lite2)")
+    ap.add_argument("--no-cold-start", action="store_true", help="do not run the contract once more in a fresh process without the settle phase")
+    ap.add_argument("--contract-only", action="store_true", help="the timed region and nothing else (what the cold-start child runs)")
     ap.add_argument("--settle-steps", type=int, default=200,
                     help="detector-only steps run before the warm-up so that the GPU is at steady clocks when the contract's W warm-up steps "
-                         "start: the first GPU process on an idle MI355X measured 71.6 k instead of 89-93 k frames/s on the 20-step run "
-                         "(0 = off; reported in the JSON line as settle_steps)")
+                         "start (0 = off; reported as settle_steps; the same run WITHOUT it is reported as cold_start)")
     ap.add_argument("--seed-offset", type=int, default=0, help="rehearsal: run this rank on the clips another rank would own")
     args = ap.parse_args()
+    if args.contract_only:
+        args.no_extras = args.no_roofline = args.no_cold_start = True
+        args.cpu_frames = 0
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # `python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, RCCL
-        # rendezvous on 127.0.0.1) BEFORE this process makes any GPU call, relay their output (rank 0 prints the JSON
-        # line) and exit with their return code.  The parent never touches the GPU and is never replaced by exec.
         return self_launch(args.gpus)
-    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cold = None
+    if world == 1 and not args.no_cold_start and args.settle_steps > 0:
+        cold = cold_start_child(args)                       # before this process initialises HIP
+    import torch
     args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -180,15 +234,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
+    rccl_ranks = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        tmo = datetime.timedelta(seconds=int(os.environ.get("VBT_BENCH_TIMEOUT_S", "180")))   # a missing rank fails the job instead of hanging it
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective buffers live
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)   # the collective really spans `world` ranks
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != dist.get_world_size():
+            raise SystemExit(f"all_reduce of ones gave {rccl_ranks}, world size is {dist.get_world_size()}")
 
-    from vbt_amd import _lib
     from vbt_amd.track import Pipeline
     n, K, W = args.clips, args.steps, args.warmup
     U = max(1, min(args.unique_steps, K + W))
@@ -197,8 +259,7 @@ def main():
     size = int(Container(MODEL).header["image_size"])
     frames_np = make_frames(seeds, 0, U, size)
     frames = torch.from_numpy(frames_np).to(dev)                      # resident in HBM before timing
-    XK = 200                                                          # steps of the extra (untimed-region) passes
-    pipe = Pipeline(MODEL, n, max_frames=max(K + W, XK) + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
+    pipe = Pipeline(MODEL, n, max_frames=K + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
     stream = torch.cuda.current_stream().cuda_stream
     fbytes = frames[0].numel()
     PH = 32                                                           # phases kept in the fixed-size result record
@@ -236,22 +297,31 @@ def main():
     else:
         rec_all = rec[None]
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
     if trace:
         print(f"[trace] rank {rank}: enqueue {1e3 * (t_enq - t0):.2f} ms, close {1e3 * (t_close - t_enq):.2f} ms, gather+fence "
               f"{1e3 * (t0 + dt - t_close):.2f} ms", file=sys.stderr)
+    per_rank = None
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tall = torch.zeros(world, dtype=torch.float64, device=cdev)
+        tall[rank] = dt_local
+        dist.all_reduce(tall)                                         # every rank's own time; the job's time is the slowest
+        per_rank = [K * n / float(t) for t in tall.tolist()]
+        dt = float(tall.max().item())
     overflow = int((ovf != 0).sum())
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = extra_measurements(torch, pipe, frames, frames_np, n, XK, U, fbytes, stream, PH)
+        extras = extra_measurements(torch, pipe, frames, frames_np, n, K, W, U, fbytes, stream, PH)
     roofline = None
     if rank == 0 and not args.no_roofline:
-        roofline = roofline_block(pipe, frames, n, stream)
+        roofline = roofline_block(pipe, n, stream)
+    del pipe
+    gc.collect()
+    configs = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_configs:
+        configs = other_configs(torch, dev)
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline(args.cpu_frames)
@@ -271,12 +341,16 @@ def main():
                                    "export-id selection + VelocityTracker on device at clip end (inside the timed region); frames resident in HBM",
                        "clips_per_gpu": n, "batch": n, "frames_per_clip": K, "model_file": os.path.basename(MODEL),
                        "weights": "seeded synthetic (PCG64), post-training int8 quantised", "parallelism": f"clip-sharded x{world}",
-                       "pipeline_depth": pipe.depth},
+                       "pipeline_depth": int(os.environ.get("VBT_PIPELINE_DEPTH", "3"))},
+            "value_is": "frames resident in HBM, after the clock-settle phase (settle_steps detector-only steps before the W warm-up steps); "
+                        "cold_start = the same run without it in a fresh process; value_h2d_inclusive = SURVEY 8d's host-to-host metric, same W and K",
+            "roofline_frac_8d": roofline_frac_8d(total_frames / dt / world, 0, n),
             "rows_emitted_rank0": int(nrows), "tracker_overflow_rank0": int(overflow),
             "clips_with_result": int((rec_all[..., 1] > 0).sum()),
             "timed_region_ms": {"enqueue": 1e3 * (t_enq - t0), "clip_close": 1e3 * (t_close - t_enq), "total": 1e3 * dt},
-            "settle_steps": int(args.settle_steps),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "settle_steps": int(args.settle_steps), "cold_start": cold,
+            "rccl_ranks": rccl_ranks, "per_rank_frames_per_s": per_rank,
+            "roofline": roofline, "cpu_baseline": cpu, "configs": configs,
         }
         out.update(extras)
         print(json.dumps(out))
@@ -292,11 +366,14 @@ def gather_records(dist, rec, world, cdev):
     return allrec.cpu().numpy().reshape(world, *rec.shape)
 
 
-def extra_measurements(torch, pipe, frames, frames_np, n, K, U, fbytes, stream, PH):
-    """Rank 0, N = 1, outside the contract's timed region: the SURVEY 8d metric (frames in pinned host memory -> rows on the
-    host, H2D and D2H included) and the detect-only / track-only splits, each over the same K steps."""
+# ----------------------------------------------------------------------------------------------------------------
+# measurements beside the contract's timed region (rank 0, N = 1)
+# ----------------------------------------------------------------------------------------------------------------
+def extra_measurements(torch, pipe, frames, frames_np, n, K, W, U, fbytes, stream, PH):
+    """SURVEY 8d's metric (frames in pinned host memory -> rows on the host, H2D and D2H inside the timed region) with the
+    contract's own W and K, and the detect-only / track-only splits."""
     out = {}
-    Kx = K
+    Kx = min(K, pipe.tracker.rows_cap // 8 - W - 8)
 
     def reset():
         torch.cuda.synchronize()
@@ -308,29 +385,33 @@ def extra_measurements(torch, pipe, frames, frames_np, n, K, U, fbytes, stream, 
     rows_host = torch.empty(n * pipe.tracker.rows_cap * 64, dtype=torch.uint8).pin_memory()
     reset()
     for i in range(2 * Uh):                     # every pinned slice once (first DMA from a pinned page is slow), twice for the staging ring
+        pipe.step(host[i % Uh], stream, track=False)
+    reset()
+    for i in range(W):                          # the contract's warm-up
         pipe.step(host[i % Uh], stream)
     torch.cuda.synchronize()
-    reset()
     t0 = time.perf_counter()
     for i in range(Kx):
-        pipe.step(host[i % Uh], stream)
+        pipe.step(host[(W + i) % Uh], stream)
     best, rows_n, nph, ovf, ph = pipe.close(cap=PH)
     counts, rows = pipe.rows_all(out=rows_host)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert int(counts.sum()) == int(rows_n.sum())
     out["value_h2d_inclusive"] = Kx * n / dt
-    out["h2d_inclusive"] = {"frames_per_s": Kx * n / dt, "ms_per_step": dt / Kx * 1e3, "steps": Kx,
+    out["h2d_inclusive"] = {"frames_per_s": Kx * n / dt, "ms_per_step": dt / Kx * 1e3, "steps": Kx, "warmup": W,
+                            "roofline_frac_8d": roofline_frac_8d(Kx * n / dt, 0, n),
                             "h2d_bytes_per_step": int(host[0].numel()), "rows_d2h_bytes": int(counts.max()) * 64 * n,
-                            "note": "uint8 frames in pinned host memory -> hipMemcpyAsync on the slot's stream (overlapped by the depth-3 "
-                                    "pipeline) -> detect+NMS+track -> clip close -> all DataFrame rows copied to pinned host memory"}
+                            "note": "uint8 frames in pinned host memory -> hipMemcpyAsync on the copy stream (two steps ahead of the "
+                                    "forwards) -> detect+NMS+track -> clip close -> all DataFrame rows copied to pinned host memory"}
     # ---- splits ----
+    Ks = min(Kx, 400)
     reset()
     for i in range(3):
         pipe.step(frames.data_ptr() + (i % U) * fbytes, stream, track=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(Kx):
+    for i in range(Ks):
         pipe.step(frames.data_ptr() + (i % U) * fbytes, stream, track=False)
     torch.cuda.synchronize()
     det_dt = time.perf_counter() - t0
@@ -338,46 +419,195 @@ def extra_measurements(torch, pipe, frames, frames_np, n, K, U, fbytes, stream, 
     pipe.step(frames.data_ptr(), stream)                                       # one real step: detections in slot 0's buffers
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipe.tracker_only_steps(Kx)
+    pipe.tracker_only_steps(Ks)
     torch.cuda.synchronize()
     trk_dt = time.perf_counter() - t0
-    out["splits"] = {"detect_only": {"frames_per_s": Kx * n / det_dt, "ms_per_step": det_dt / Kx * 1e3,
+    out["splits"] = {"detect_only": {"frames_per_s": Ks * n / det_dt, "ms_per_step": det_dt / Ks * 1e3,
                                      "note": f"detector + decode + NMS, {pipe.depth} forwards in flight, no tracker"},
-                     "track_only": {"clip_frames_per_s": Kx * n / trk_dt, "us_per_step": trk_dt / Kx * 1e6,
+                     "track_only": {"clip_frames_per_s": Ks * n / trk_dt, "us_per_step": trk_dt / Ks * 1e6,
                                     "note": "OC-SORT step of all clips on one frame's detections, repeated"}}
     reset()
     return out
 
 
-def roofline_block(pipe, frames, n, stream):
-    """Dominant kernel family by HIP-event time on the launch stream (one forward in flight)."""
+def _timed(torch, body, reps=2):
+    """Best of `reps` runs of body() (which must end with everything on the host), seconds."""
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        body()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def other_configs(torch, dev):
+    """BASELINE.json configs 2, 4 and 5 and the small-batch points, each as whole-clip runs (clip close + rows on the host
+    inside the timed region), frames resident in HBM."""
+    from vbt_amd import shard, synth
+    from vbt_amd.track import Pipeline
+    out = {}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:                                   # a diagnostic configuration must not cost the headline
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        gc.collect()
+
+    # ---- config 2 as literally written: one clip, one frame per step (batch 1), and batch 8 ----
+    def small_batch(nb, T):
+        U = 64
+        fr = torch.from_numpy(make_frames(list(range(nb)), 0, U)).to(dev)
+        fb = fr[0].numel()
+        pipe = Pipeline(MODEL, nb, max_frames=T, fps=60.0)
+
+        def body():
+            pipe.reset()
+            for t in range(T):
+                pipe.step(fr.data_ptr() + (t % U) * fb, stream)
+            pipe.close(cap=64)
+            pipe.rows_all()
+        dt = _timed(torch, body)
+        fps = nb * T / dt
+        return {"frames_per_s": fps, "ms_per_step": dt / T * 1e3, "batch": nb, "frames_per_clip": T, "roofline_frac_8d": roofline_frac_8d(fps, 0, nb),
+                "note": f"{nb} clip(s), one frame per clip per step (the forward is a replayed hipGraph), {pipe.depth} forwards in flight"}
+    guarded("b1", lambda: small_batch(1, 2048))
+    guarded("b8", lambda: small_batch(8, 1024))
+
+    # ---- config 2's clip on the time-batched path: ONE clip of 4096 frames, 64 consecutive frames per detector batch ----
+    def clip1():
+        T, F, U = 4096, 64, 256
+        bg = synth.background(0)
+        base = np.stack([synth.render(bg, t) for t in range(U)])
+        fr = torch.from_numpy(np.concatenate([base, base[:F]])).to(dev)          # a cycle of U frames: every run of F is contiguous
+        pipe = Pipeline(MODEL, F, max_frames=T, fps=60.0, tracker_clips=1)
+        res = {}
+
+        def body():
+            pipe.reset()
+            for f0 in range(0, T, F):
+                s = f0 % U
+                pipe.step_runs(fr[s:s + F], [(0, 0, F, f0 + 1)])
+            b, r, p, o, _ = pipe.close(cap=512)
+            pipe.rows_all()
+            res.update(rows=int(r.sum()), phases=int(p.sum()))
+        dt = _timed(torch, body)
+        fps = T / dt
+        return {"frames_per_s": fps, "ms_per_step": dt / (T // F) * 1e3, "batch": F, "clips": 1, "frames_per_clip": T, "roofline_frac_8d": roofline_frac_8d(fps, 0, F),
+                "rows": res["rows"], "phases": res["phases"],
+                "note": "one 4096-frame clip, 64 consecutive frames per detector batch, OC-SORT walks the run in frame order inside one launch "
+                        "(vbt_tracker_update_from_detections_seq): bound by the sequential tracker walk, not by the detector"}
+    guarded("clip1_time_batched", clip1)
+
+    # ---- config 5's per-GPU shape: the 34-clip corpus (real frame counts / fps) on ONE GPU, time-batched ----
+    def corpus():
+        meta = json.load(open(CORPUS_META))
+        keys = sorted(meta)
+        lengths = np.array([meta[k][0] for k in keys])
+        fps_c = np.array([meta[k][1] for k in keys])
+        U, slots = 8, 64
+        base = np.stack([np.stack([synth.render(synth.background(int(k), 320), 11 * u) for u in range(U)]) for k in keys])
+        fr = torch.from_numpy(np.concatenate([base, base], axis=1)).to(dev)      # [clip][2U]
+        steps = shard.run_schedule(lengths, slots)
+        pipe = Pipeline(MODEL, slots, max_frames=int(lengths.max()), fps=fps_c, tracker_clips=len(keys))
+        res = {}
+
+        def body():
+            pipe.reset()
+            for step in steps:
+                pipe.step_runs([fr[c, (f0 - 1) % U:(f0 - 1) % U + nf] for c, _, nf, f0 in step], step)
+            b, r, p, o, _ = pipe.close(cap=512)
+            pipe.rows_all()
+            res.update(rows=int(r.sum()), overflow=int((o != 0).sum()))
+        dt = _timed(torch, body)
+        total = int(lengths.sum())
+        fps = total / dt
+        return {"frames_per_s": fps, "ms_per_step": dt / len(steps) * 1e3, "batch": slots, "clips": len(keys), "frames": total, "steps": len(steps),
+                "roofline_frac_8d": roofline_frac_8d(fps, 0, slots), "rows": res["rows"], "tracker_overflow": res["overflow"],
+                "longest_run": max(nf for s in steps for _, _, nf, _ in s),
+                "note": "34 synthetic clips with the reference corpus' frame counts (699...3243) and frame rates; every step deals the 64 "
+                        "detector slots to the clips in proportion to the frames they have left (shard.run_schedule)"}
+    guarded("corpus_1gpu", corpus)
+
+    # ---- config 4: EfficientDet-Lite2 448x448 + OC-SORT, 64 clips per step ----
+    def lite2():
+        nb, T, U = 64, 120, 4
+        os.environ["VBT_PLAN_FILE"] = PLAN_LITE2
+        try:
+            fr = torch.from_numpy(make_frames(list(range(nb)), 0, U, 448)).to(dev)
+            fb = fr[0].numel()
+            pipe = Pipeline(MODEL_LITE2, nb, max_frames=T, fps=30.0)
+        finally:
+            os.environ["VBT_PLAN_FILE"] = PLAN_LITE0
+
+        def body():
+            pipe.reset()
+            for t in range(T):
+                pipe.step(fr.data_ptr() + (t % U) * fb, stream)
+            pipe.close(cap=64)
+            pipe.rows_all()
+        dt = _timed(torch, body)
+        fps = nb * T / dt
+        return {"frames_per_s": fps, "ms_per_step": dt / T * 1e3, "batch": nb, "frames_per_clip": T, "roofline_frac_8d": roofline_frac_8d(fps, 2, nb),
+                "model_file": os.path.basename(MODEL_LITE2), "plan": os.path.basename(PLAN_LITE2) + f".b{nb}.f0",
+                "algorithmic_bytes_per_frame": alg_bytes_per_frame(2, nb)}
+    if os.path.exists(MODEL_LITE2):
+        guarded("lite2_448", lite2)
+    return out
+
+
+def roofline_block(pipe, n, stream):
+    """Dominant kernel family of the forward: all of its launches timed as ONE HIP-event bracket on the launch stream (one
+    forward in flight, pipeline idle), i.e. without an event pair around every short launch; the committed rocprofv3
+    --kernel-trace --stats summary of the same plan (profiles/) gives the same average launch duration.
+    achieved = SURVEY 8d algorithmic bytes per launch / that duration; traffic = PMC HBM bytes per launch of the same plan."""
     from vbt_amd import _lib
     L = _lib.lib()
     stats = (_lib.KernelStat * 16)()
     cnt = ctypes.c_int()
     _lib.check(L.vbt_model_kernel_stats(pipe.interpreter.handle, n, stats, 16, ctypes.byref(cnt)))
     ms = (ctypes.c_double * 16)()
-    _lib.check(L.vbt_model_profile(pipe.interpreter.handle, frames.data_ptr(), n, 10, stream, ms, 16))
+    _lib.check(L.vbt_model_profile_families(pipe.interpreter.handle, n, 20, stream, ms, 16))
     fam = max(range(cnt.value), key=lambda i: ms[i])
     s = stats[fam]
     name = s.name.decode()
     per_launch_s = ms[fam] * 1e-3 / s.launches
     achieved = (s.algorithmic_bytes / s.launches) / per_launch_s
-    traffic = counters = None   # from the separate rocprofv3 --pmc passes of this same plan (profiles/, tools/make_profile_summary.py)
-    try:
-        tj = json.load(open(COUNTERS_JSON))
-        fj = tj["families"].get(name)
-        if tj.get("batch") == n and fj and fj["launches"] == s.launches:
-            traffic = fj["hbm_bytes_per_launch"]
-        counters = tj.get("derived")
-    except (OSError, ValueError, KeyError):
-        pass
+    traffic = counters = prof_us = src = None   # from the separate rocprofv3 --pmc passes of this same plan (tools/make_profile_summary.py)
+    for path in COUNTERS:
+        try:
+            tj = json.load(open(path))
+            fj = tj["families"].get(name)
+            if tj.get("batch") == n and fj and fj["launches"] == s.launches:
+                traffic = fj["hbm_bytes_per_launch"]
+                prof_us = fj["kernel_us_per_forward"] / fj["launches"]
+                counters = tj.get("derived", {}).get("per_family", {}).get(name)
+                src = os.path.basename(path)
+                break
+        except (OSError, ValueError, KeyError):
+            continue
+    limiter = None
+    if counters:
+        # which roof the counters point at: neither HBM nor MFMA is the limiter when both sit far below their peaks
+        hbm_frac = (traffic / per_launch_s / HBM_PEAK) if traffic else 0.0
+        mfma = counters.get("mfma_busy_frac", 0.0)
+        limiter = {"hbm_traffic_frac": hbm_frac, "mfma_busy_frac": mfma, "wait_any_frac": counters.get("wait_any_frac"),
+                   "active_inst_frac": counters.get("active_inst_frac"),
+                   "reading": "vector-ALU issue + waits between phases; neither the HBM nor the MFMA roof" if max(hbm_frac, mfma) < 0.5
+                   else ("hbm" if hbm_frac >= mfma else "mfma")}
     return {"bound": "hbm", "kernel": name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": traffic, "launches_per_step": s.launches,
-            "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": s.algorithmic_bytes / s.launches,
-            "hbm_traffic_GBps": (traffic / per_launch_s / 1e9) if traffic else None,
-            "counters": counters,
-            "families_ms_per_step": {stats[i].name.decode(): round(ms[i], 4) for i in range(cnt.value)},
+            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "frac_traffic": (traffic / per_launch_s / HBM_PEAK) if traffic else None,
+            "launches_per_step": s.launches, "avg_launch_us": per_launch_s * 1e6, "profiles_avg_launch_us": prof_us, "profiles_source": src,
+            "algorithmic_bytes_per_launch": s.algorithmic_bytes / s.launches,
+            "bound_note": "`bound` names the SURVEY 8d roofline the fraction is taken against (HBM, algorithmic bytes of the unfused graph); "
+                          "`limiter` is what the PMC counters of this family say actually limits it",
+            "limiter": limiter,
+            "families_ms_per_step": {stats[i].name.decode(): round(ms[i], 4) for i in range(cnt.value) if ms[i] > 0},
             "whole_net_algorithmic_GBps": sum(stats[i].algorithmic_bytes for i in range(cnt.value)) /
             (sum(ms[i] for i in range(cnt.value)) * 1e-3) / 1e9}
 

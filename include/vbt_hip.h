@@ -139,6 +139,10 @@ int vbt_model_profile_overlap(vbt_model* m, int B, int reps, int nstreams, float
 int vbt_model_profile(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream,
                       double* ms_out, int cap);
 
+/* The same, measured the way rocprofv3 --kernel-trace sees it: all launches of a family back to back between ONE pair of HIP
+ * events (`reps` passes), no event pair around every short launch.  ms_out[i] = milliseconds per pass of family i. */
+int vbt_model_profile_families(vbt_model* m, int B, int reps, void* stream, double* ms_out, int cap);
+
 /* ------------------------------------------------------------------ tracker -----------------
  * Replaces ocsort.OCSort (reference track.py:17,157,186-199), the row assembly of
  * reference track.py:189-234 and the export id selection of track.py:107-115.

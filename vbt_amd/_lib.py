@@ -55,6 +55,7 @@ _SIGS = {
     "vbt_resize_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vbt_model_kernel_stats": (c_int, [c_void_p, c_int, ctypes.POINTER(KernelStat), c_int, ctypes.POINTER(c_int)]),
     "vbt_model_profile": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_double), c_int]),
+    "vbt_model_profile_families": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(c_double), c_int]),
     "vbt_model_profile_steps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.POINTER(StepTime), c_int, ctypes.POINTER(c_int)]),
     "vbt_model_profile_overlap": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "vbt_tracker_create": (c_int, [c_int, c_int, ctypes.POINTER(TrackerParams), c_int, ctypes.POINTER(c_void_p)]),

@@ -3384,6 +3384,40 @@ int vbt_model_profile(vbt_model* m, const uint8_t* frames_dev, int B, int reps, 
   return rc;
 }
 
+// One bracket per kernel family: all launches of family i of the plan back to back on `stream` (`reps` passes between ONE pair
+// of HIP events), so ms_out[i] / launches is an average launch duration without the ~3 us a pair of events around every short
+// launch adds - the figure rocprofv3 --kernel-trace reports for the same kernels (profiles/) to within the dispatch gap.
+int vbt_model_profile_families(vbt_model* m, int B, int reps, void* stream, double* ms_out, int cap) {
+  if (!m || !ms_out || cap < F_COUNT || reps < 1) { set_error("bad argument"); return VBT_ERR_ARG; }
+  if (B < 1 || B > m->max_batch) { set_error("bad batch"); return VBT_ERR_CAPACITY; }
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  VBT_HIP_CHECK(hipEventCreate(&e0));
+  VBT_HIP_CHECK(hipEventCreate(&e1));
+  int rc = VBT_OK;
+  for (int f = 0; f < F_COUNT && rc == VBT_OK; f++) {
+    ms_out[f] = 0.0;
+    bool any = false;
+    for (const Step& s : m->steps) any |= s.family == f;
+    if (!any) continue;
+    for (int pass = 0; pass < 2 && rc == VBT_OK; pass++) {   // pass 0: warm (code objects, caches)
+      const int n = pass == 0 ? 1 : reps;
+      (void)hipEventRecord(e0, st);
+      for (int r = 0; r < n && rc == VBT_OK; r++)
+        for (const Step& s : m->steps)
+          if (s.family == f && rc == VBT_OK) rc = launch_step(m, s, B, st, m->frames_stage, m->out_boxes, m->out_scores, m->out_classes, m->out_counts);
+      (void)hipEventRecord(e1, st);
+      if (hipStreamSynchronize(st) != hipSuccess) { set_error("stream sync failed"); rc = VBT_ERR_HIP; break; }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (pass == 1) ms_out[f] = (double)ms / reps;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
 // Per-launch timing of the plan (one forward in flight, HIP events around every launch): step i of the execution list ->
 // family name, index of the last graph op it covers, kernel variant and milliseconds (average over `reps`).
 int vbt_model_profile_steps(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream, vbt_step_time* out, int cap, int* n) {
