@@ -45,32 +45,12 @@ typedef struct vbt_model vbt_model;
 
 /* container_path: a VBTM model container (vbt_amd/container.py); max_batch frames per vbt_detect. */
 int vbt_model_create(const char* container_path, int device, int max_batch, vbt_model** out);
-/* flags: VBT_MODEL_NO_FUSION runs every graph op as its own kernel (every tensor readable by
- * vbt_model_read_tensor); the default fuses MBConv / SeparableConv blocks on LDS tiles.
- * vbt_model_create == _ex with VBT_MODEL_DEFAULT_FLAGS (or the integer in the environment variable
- * VBT_FUSION_FLAGS). */
-#define VBT_MODEL_NO_FUSION 1
-#define VBT_MODEL_NO_MBCONV_FUSION 2
-#define VBT_MODEL_NO_SEPCONV_FUSION 4
-#define VBT_MODEL_NO_NODE_FUSION 16  /* keep BiFPN resample/add ops out of the fused SeparableConv kernels */
-#define VBT_MODEL_SINGLE_STREAM 32   /* do not split the batch over side streams */
-#define VBT_MODEL_NO_GRAPH 64        /* never replay the forward from a captured hipGraph */
-#define VBT_MODEL_NO_HEAD_BATCHING 128 /* one launch per head layer and level instead of one per layer */
-#define VBT_MODEL_NO_STEM_FUSION 256  /* stem conv as its own kernel instead of stem + first SeparableConv fused */
-#define VBT_MODEL_NODE_CHAIN 1024     /* experimental: runs of small BiFPN nodes as ONE launch, one workgroup per image (node_chain.h) */
-#define VBT_MODEL_CHUNK48 2048        /* heuristic plan: 48-channel chunks in fused MBConv blocks whose expanded width allows it */
-#define VBT_MODEL_IMAGE_BLOCKS 512    /* heuristic plan: whole-image MBConv kernel wherever it applies (autotuning decides otherwise) */
-#define VBT_MODEL_TILE128 16384       /* heuristic plan: 128-pixel tiles in the fused MBConv blocks that allow them */
-#define VBT_MODEL_NO_BAND 8192        /* do not use the row-band SeparableConv kernel of the BiFPN nodes / head layers */
-#define VBT_MODEL_NO_EXPDW 4096       /* do not use the whole-image expand+depthwise kernel of the low-resolution MBConv blocks */
-#define VBT_MODEL_NO_AUTOTUNE 8     /* keep the heuristic plan (most fused alternative, default kernel variants) */
+/* flags = 0 (VBT_MODEL_DEFAULT_FLAGS): the fused, autotuned execution plan.  The plan-shaping flags used by the parity tests and
+ * the tuning tools are lab equipment and live in vbt_hip_diag.h.  vbt_model_create == _ex with flags 0 (or the integer in the
+ * environment variable VBT_FUSION_FLAGS). */
 #define VBT_MODEL_DEFAULT_FLAGS 0
 int vbt_model_create_ex(const char* container_path, int device, int max_batch, int flags, vbt_model** out);
 void vbt_model_destroy(vbt_model* m);
-/* 1 if graph tensor `tensor_id` is written to HBM by the execution plan, 0 if it only exists in LDS */
-int vbt_model_tensor_materialized(const vbt_model* m, int tensor_id);
-/* kernels launched per forward */
-int vbt_model_num_launches(const vbt_model* m);
 /* shape = {max_batch, H, W, 3} */
 int vbt_model_input_shape(const vbt_model* m, int shape[4]);
 int vbt_model_num_tensors(const vbt_model* m);
@@ -88,9 +68,6 @@ int vbt_model_tensor_shape(const vbt_model* m, int tensor_id, int shape[3]);
 int vbt_detect(vbt_model* m, const uint8_t* frames, int B, int frames_on_device, void* stream,
                float* boxes, float* scores, float* classes, int32_t* counts, int outputs_on_device);
 
-/* Parity/debug: copy graph tensor `tensor_id` ([B,H,W,C] int8) of the last vbt_detect to host. */
-int vbt_model_read_tensor(vbt_model* m, int tensor_id, int B, int8_t* host_out);
-
 /* Enqueue only (no copies, no sync): frames and outputs are device pointers. Used by the fused
  * pipeline and by bench.py inside HIP-event brackets. */
 int vbt_detect_async(vbt_model* m, const uint8_t* frames_dev, int B, void* stream,
@@ -102,46 +79,12 @@ int vbt_detect_async(vbt_model* m, const uint8_t* frames_dev, int B, void* strea
  * queues, whatever a framework's stream pool has been used for before. */
 int vbt_stream_create(int device, void** stream_out);
 int vbt_stream_destroy(void* stream);
-/* *shared = 1 when the two streams sit on one hardware queue (their kernels cannot overlap): a single wave spins `us`
- * microseconds on each and the pair is timed.  The device must be otherwise idle. */
-int vbt_streams_share_queue(void* a, void* b, int us, int* shared);
 
 /* preprocess_image (reference odt.py:10-19): bilinear resize (half-pixel centres, float32) of
  * uint8 [B,H,W,3] frames to [B,h,w,3] + truncating uint8 cast; swap_rb != 0 also swaps channels 0
  * and 2 (cv2 BGR -> RGB, reference track.py:171).  src/dst are host or device pointers. */
 int vbt_resize_frames(const uint8_t* src, int B, int H, int W, int src_on_device, uint8_t* dst, int h, int w,
                       int dst_on_device, int swap_rb, int device, void* stream);
-
-/* Per-kernel-family accounting of the last enqueued forward: fills up to `cap` entries.
- * Algorithmic bytes = inputs read once + output written once + weights once. */
-typedef struct {
-  char name[32];
-  int launches;
-  double algorithmic_bytes;
-  double macs;
-} vbt_kernel_stat;
-int vbt_model_kernel_stats(const vbt_model* m, int B, vbt_kernel_stat* out, int cap, int* n);
-/* Per-launch profile of the execution plan (one forward in flight, HIP events around every launch; average of `reps`):
- * entry i = launch i of the forward.  `op` / `first_op` = last / first graph op the launch covers. */
-typedef struct {
-  char family[32];
-  int op, first_op, variant;
-  double ms, algorithmic_bytes, macs;
-} vbt_step_time;
-int vbt_model_profile_steps(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream, vbt_step_time* out, int cap, int* n);
-/* Measurement: each plan step `reps` times on one stream (single_ms, per launch) and on `nstreams` streams at once
- * (conc_ms, wall time per launch): how much of a step the other forwards in flight can hide. */
-int vbt_model_profile_overlap(vbt_model* m, int B, int reps, int nstreams, float* single_ms, float* conc_ms, int cap, int* n);
-
-/* Time each kernel family with HIP events on `stream` over `reps` forwards of batch B
- * (frames must be device-resident). ms_out[i] = average milliseconds per forward spent in
- * family i (same order as vbt_model_kernel_stats). */
-int vbt_model_profile(vbt_model* m, const uint8_t* frames_dev, int B, int reps, void* stream,
-                      double* ms_out, int cap);
-
-/* The same, measured the way rocprofv3 --kernel-trace sees it: all launches of a family back to back between ONE pair of HIP
- * events (`reps` passes), no event pair around every short launch.  ms_out[i] = milliseconds per pass of family i. */
-int vbt_model_profile_families(vbt_model* m, int B, int reps, void* stream, double* ms_out, int cap);
 
 /* ------------------------------------------------------------------ tracker -----------------
  * Replaces ocsort.OCSort (reference track.py:17,157,186-199), the row assembly of

@@ -1,4 +1,4 @@
-"""CPU-side checks: the C-ABI library loads and exports every symbol include/vbt_hip.h declares
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/*.h declares
 (no compute without a GPU), loud failure without a GPU, export logic, clip sharding, gloo gather."""
 import os
 import re
@@ -12,9 +12,12 @@ from conftest import GOLDEN, ROOT
 
 
 def _declared_in_header():
-    txt = open(os.path.join(ROOT, "include", "vbt_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(vbt_[a-z_0-9]+)\s*\(", txt)))
+    names = set()
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):          # vbt_hip.h (the boundary) + vbt_hip_diag.h (measurement / tests)
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(vbt_[a-z_0-9]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

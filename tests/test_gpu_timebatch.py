@@ -159,7 +159,7 @@ def test_config2_full_length_clip(model_path):
         ref.step(fd[t:t + 1])
     rb, rr, rn, ro, rph = ref.close(cap=512)
     rc, rrows = ref.rows_all()
-    assert rr[0] > 1500 and rn[0] >= 8 and ro[0] == 0
+    assert rr[0] > 1500 and rn[0] >= 2 and ro[0] == 0
     pipe = Pipeline(model_path, F, max_frames=T, fps=60.0, tracker_clips=1)
     for t0 in range(0, T, F):
         pipe.step_runs(fd[t0:t0 + F], [(0, 0, F, t0 + 1)])

@@ -30,6 +30,26 @@ def _headers():
            [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include")) if f.endswith(".h")]
 
 
+# Kernel headers whose change cannot affect a translation unit's code (launchers.h shows every argument struct to every unit, but
+# a unit only instantiates the kernels of its own headers).  Anything not listed here is a dependency of every unit.
+KERNEL_HEADERS = {"band_block.h", "expdw_block.h", "stem_block.h", "image_block.h", "node_chain.h", "fused_block.h"}
+UNIT_KERNEL_HEADERS = {
+    "k_band.hip": {"band_block.h", "expdw_block.h", "stem_block.h", "fused_block.h"},
+    "k_image.hip": {"image_block.h", "node_chain.h", "fused_block.h"},
+    "k_fused_mbconv.hip": {"fused_block.h"},
+    "k_fused_sepconv.hip": {"fused_block.h"},
+    "tracker.hip": set(),
+    "frames.hip": set(),
+}
+
+
+def _unit_headers(unit, hdrs):
+    mine = UNIT_KERNEL_HEADERS.get(unit)
+    if mine is None:            # the planner (detector.hip) and anything new: every header
+        return hdrs
+    return [h for h in hdrs if os.path.basename(h) not in KERNEL_HEADERS or os.path.basename(h) in mine]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -54,7 +74,7 @@ def build(force=False, verbose=True):
     jobs = []
     for s in sources():
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale(obj, [src] + _unit_headers(s, hdrs)):
             jobs.append([hipcc] + FLAGS + ["-c", "-o", obj, src])
 
     def run(cmd):

@@ -188,6 +188,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #define VBT_BD_HEAD_MAXPX 240
 #endif
 constexpr int BD_HEAD_WAVES = VBT_BD_HEAD_WAVES, BD_HEAD_MAXPX = VBT_BD_HEAD_MAXPX;
+#ifdef VBT_DEFINE_BAND_KERNELS   // the two entry points are not templates: exactly one translation unit (k_band.hip) defines them
 __global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   int pi = 0;
@@ -202,3 +203,4 @@ __global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_kernel(BandArgs a
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   sepconv_band_body<BD_WAVES>(a, (int)blockIdx.x, bd_smem_dyn);
 }
+#endif  // VBT_DEFINE_BAND_KERNELS

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/vbt_hip.h"
+#include "../../include/vbt_hip_diag.h"
 
 namespace vbt {
 

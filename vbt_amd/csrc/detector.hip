@@ -24,11 +24,9 @@
 #include <type_traits>
 #include <tuple>
 
-#include "common.h"
+#include "launchers.h"   // dev_common.h + the argument structs / tile constants of every kernel family + the launchers
 
 namespace vbt {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -37,140 +35,6 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-
-// ------------------------------------------------------------------------------------------
-// device helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int requant(int acc, float mult, int zp, int lo, int hi) {
-  float t = (float)acc * mult;
-  t = fminf(fmaxf(t, -65536.0f), 65536.0f);
-  int q = (int)__builtin_rintf(t) + zp;  // v_rndne_f32: round-to-nearest-even
-  return min(max(q, lo), hi);
-}
-__device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
-  return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)(d & 255) << 24);
-}
-
-// The same requantisation in 5 VALU ops + 1 pack op per element: clamp(rne(t) + zp, lo, hi) ==
-// clamp(rne(t), lo - zp, hi - zp) + zp because every quantity after rne() is an exact small integer in
-// fp32; the result is produced in the unsigned domain (q + 128 in [0,255]) so v_cvt_pk_u8_f32 can pack
-// it, and one XOR 0x80808080 per dword turns the four bytes back into int8.
-struct Rq {
-  float lo_f, hi_f, off;  // lo - zp, hi - zp, zp + 128
-  int full;               // lo == -128 && hi == 127: the clamp is the [0,255] saturation of v_cvt_pk_u8_f32 itself
-};
-__host__ __device__ inline Rq make_rq(int zp, int lo, int hi) {
-  return Rq{(float)(lo - zp), (float)(hi - zp), (float)(zp + 128), (lo <= -128 && hi >= 127) ? 1 : 0};
-}
-__device__ __forceinline__ float rq_u8(float accf, float mult, const Rq& q) {
-  float r = __builtin_rintf(accf * mult);
-  return __builtin_amdgcn_fmed3f(r, q.lo_f, q.hi_f) + q.off;
-}
-__device__ __forceinline__ unsigned pack4_u8f(float a, float b, float c, float d) {  // -> int8 x4
-  unsigned v = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0);
-  v = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, v);
-  v = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, v);
-  v = __builtin_amdgcn_cvt_pk_u8_f32(d, 3, v);
-  return v ^ 0x80808080u;
-}
-// acc already contains the bias (accumulators are initialised with it).  The multiply and the offset add use the
-// packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32: two IEEE single ops per instruction, same results).
-typedef float v2f __attribute__((ext_vector_type(2)));
-template <int FULLK = -1>
-__device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, const Rq& q) {
-  v2f t0 = (v2f){(float)acc[0], (float)acc[1]} * (v2f){mu.x, mu.y};
-  v2f t1 = (v2f){(float)acc[2], (float)acc[3]} * (v2f){mu.z, mu.w};
-  const v2f off = {q.off, q.off};
-  if (FULLK == 1 || (FULLK < 0 && q.full)) {
-    // rne(t) by the float adder: t + 1.5*2^23 has ulp 1 and an even base, so the sum is exactly 1.5*2^23 + rne(t) for
-    // |t| < 2^22; adding (zp + 128 - 1.5*2^23) is exact again and the u8 conversion saturates to [0, 255], which IS the
-    // clamp to int8 (+128).  |t| >= 2^22 stays far outside [0, 255] on the same side, i.e. saturates like the clamp.
-    // Two packed adds replace four v_rndne + one packed add.
-    const v2f magic = {12582912.0f, 12582912.0f};
-    const v2f back = {q.off - 12582912.0f, q.off - 12582912.0f};
-    v2f r0 = (t0 + magic) + back;
-    v2f r1 = (t1 + magic) + back;
-    return pack4_u8f(r0.x, r0.y, r1.x, r1.y);
-  }
-  v2f r0 = {__builtin_amdgcn_fmed3f(__builtin_rintf(t0.x), q.lo_f, q.hi_f), __builtin_amdgcn_fmed3f(__builtin_rintf(t0.y), q.lo_f, q.hi_f)};
-  v2f r1 = {__builtin_amdgcn_fmed3f(__builtin_rintf(t1.x), q.lo_f, q.hi_f), __builtin_amdgcn_fmed3f(__builtin_rintf(t1.y), q.lo_f, q.hi_f)};
-  r0 = r0 + off;
-  r1 = r1 + off;
-  return pack4_u8f(r0.x, r0.y, r1.x, r1.y);
-}
-// exact n / d for 0 <= n < 2^20, 1 <= d <= 4096 without the ~40-instruction integer division
-__device__ __forceinline__ int fdiv_small(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
-// reciprocal for fdiv_small: one v_rcp_f32 (1 ulp) instead of the IEEE division sequence.  (n + 0.5) / d lies at least
-// 0.5 / d away from an integer and the product carries < 2^-22 relative error, so the floor is exact for n < 2^20.
-__device__ __forceinline__ float frcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
-__device__ __forceinline__ v4i v4i_from(const int4& b) { return (v4i){b.x, b.y, b.z, b.w}; }
-
-__device__ __forceinline__ unsigned rq_pack_i(const v4i& acc, const int4& b, const float4& mu, const Rq& q) {
-  const v4i a2 = {acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w};
-  return rq_pack_b(a2, mu, q);
-}
-
-// ---- int8 ADD, XNNPACK qs8-vadd-minmax: q = clamp(((bias + a*am + b*bm) >> shift) + z_out, lo, hi).  The kernel's
-// int16 / int8 saturating packs are monotone and the activation range lies inside int8, so the chain of saturations equals
-// one clamp; it is applied before the zero point is added (lo - z_out, hi - z_out), and `off` = z_out + 128 moves the
-// result to its u8 image so that four of them pack with shifts (no masks) and one XOR restores int8.
-struct AddQ { int bias, am, bm, shift, lo, hi, off; };
-static inline AddQ make_addq(const AddParams& p, int z_out, int lo, int hi) {
-  return AddQ{p.bias, p.am, p.bm, p.shift, lo - z_out, hi - z_out, z_out + 128};
-}
-__device__ __forceinline__ int addq_u8(int a, int b, const AddQ& q) {  // -> q + 128 in [0, 255]
-  const int t = (q.bias + __mul24(a, q.am) + __mul24(b, q.bm)) >> q.shift;   // |am|, |bm| < 2^22, a, b int8: 24-bit products
-  return min(max(t, q.lo), q.hi) + q.off;
-}
-__device__ __forceinline__ unsigned addq4(unsigned ua, unsigned ub, const AddQ& q) {  // four int8 lanes per dword
-  unsigned r = 0;
-#pragma unroll
-  for (int e = 0; e < 4; e++)
-    r |= (unsigned)addq_u8((int)(int8_t)(ua >> (8 * e)), (int)(int8_t)(ub >> (8 * e)), q) << (8 * e);
-  return r ^ 0x80808080u;
-}
-
-struct Epi {  // requantisation parameters of one conv
-  const int* bias;    // folded bias, padded to NB*64
-  const float* mult;  // padded to NB*64
-  int zp, lo, hi;
-  Rq rq;
-};
-
-// Lane (r = lane&15 pixel, g = lane>>4) holds acc[t][j] = channel nb*64 + 16g + 4t + j of pixel r.
-__device__ __forceinline__ void store_tile(const v4i acc[4], const Epi& e, int8_t* __restrict__ out, long m, int N,
-                                           int nb, int g) {
-  int c0 = nb * 64 + 16 * g;
-  if (c0 >= N) return;
-  unsigned d[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    int4 b = *(const int4*)(e.bias + c0 + 4 * t);
-    float4 mu = *(const float4*)(e.mult + c0 + 4 * t);
-    d[t] = rq_pack_i(acc[t], b, mu, e.rq);
-  }
-  int8_t* o = out + m * N + c0;
-  if ((N & 15) == 0) {
-    *(uint4*)o = make_uint4(d[0], d[1], d[2], d[3]);
-  } else if ((N & 3) == 0) {
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-      if (c0 + 4 * t < N) *(unsigned*)(o + 4 * t) = d[t];
-  } else {
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (c0 + 4 * t + j < N) o[4 * t + j] = (int8_t)(d[t] >> (8 * j));
-  }
-}
-
-#include "fused_block.h"  // (inside namespace vbt)
-#include "stem_block.h"
-#include "image_block.h"
-#include "node_chain.h"
-#include "expdw_block.h"
-#include "band_block.h"
 
 // ------------------------------------------------------------------------------------------
 // pointwise conv on the gfx950 double-rate int8 MFMA (v_mfma_i32_16x16x64_i8: same 16 issue cycles as the legacy
@@ -1063,6 +927,12 @@ struct vbt_model {
   hipStream_t cap_stream = nullptr;
   int graph_max_batch = 0;  // 0 = graphs off
   std::vector<void*> owned;  // device allocations to free
+  // Parameter pool: weights, biases, multipliers and argument tables are sub-allocated from a few large device chunks and
+  // mirrored on the host; flush_uploads() brings a chunk up to date with ONE copy (a model used to issue ~1 800 small blocking
+  // hipMemcpy calls at creation).  Off under VBT_DEBUG_FENCE, where every buffer ends at its own allocation boundary.
+  struct PoolChunk { char* dev; std::vector<char> host; size_t used, flushed; };
+  std::vector<PoolChunk> pool;
+  bool pool_dirty = false;
   int last_B = 0;
 };
 
@@ -1092,11 +962,50 @@ static hipError_t fenced_malloc(vbt_model* m, void** out, size_t bytes) {
   return hipSuccess;
 }
 
+constexpr size_t POOL_CHUNK = 32u << 20;
+static int pool_alloc(vbt_model* m, size_t bytes, void** dev, char** host) {
+  bytes = (bytes + 255) & ~(size_t)255;   // 256-byte alignment, like hipMalloc
+  if (m->pool.empty() || m->pool.back().used + bytes > m->pool.back().host.size()) {
+    vbt_model::PoolChunk c;
+    c.dev = nullptr; c.used = 0; c.flushed = 0;
+    const size_t cap = std::max(POOL_CHUNK, bytes);
+    VBT_HIP_CHECK(hipMalloc((void**)&c.dev, cap));
+    m->owned.push_back(c.dev);
+    c.host.assign(cap, 0);
+    m->pool.push_back(std::move(c));
+  }
+  vbt_model::PoolChunk& c = m->pool.back();
+  *dev = c.dev + c.used;
+  *host = c.host.data() + c.used;
+  c.used += bytes;
+  m->pool_dirty = true;
+  return VBT_OK;
+}
+// Everything uploaded since the last flush reaches the device: one copy per chunk that grew.  Called before any kernel of
+// the model can run (launch_step).
+static int flush_uploads(vbt_model* m) {
+  if (!m->pool_dirty) return VBT_OK;
+  for (auto& c : m->pool)
+    if (c.used > c.flushed) {
+      VBT_HIP_CHECK(hipMemcpy(c.dev + c.flushed, c.host.data() + c.flushed, c.used - c.flushed, hipMemcpyHostToDevice));
+      c.flushed = c.used;
+    }
+  m->pool_dirty = false;
+  return VBT_OK;
+}
+
 template <typename T>
 static int upload(vbt_model* m, const std::vector<T>& h, T** d) {
   size_t bytes = std::max<size_t>(h.size() * sizeof(T), 16);
-  VBT_HIP_CHECK(fenced_malloc(m, (void**)d, bytes + 64));
-  if (!h.empty()) VBT_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (fence_on()) {
+    VBT_HIP_CHECK(fenced_malloc(m, (void**)d, bytes + 64));
+    if (!h.empty()) VBT_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return VBT_OK;
+  }
+  char* host = nullptr;
+  int rc = pool_alloc(m, bytes + 64, (void**)d, &host);   // (+64: kernels read K-padding bytes past a weight row's end)
+  if (rc) return rc;
+  if (!h.empty()) memcpy(host, h.data(), h.size() * sizeof(T));
   return VBT_OK;
 }
 
@@ -2418,18 +2327,9 @@ static ImageGeom image_geom(const vbt_model* m, const Step& s) {
   g.ok = s.ib.data != nullptr && units <= 4 && g.lds <= 160 * 1024 && s.ib.bytes <= 16 * IB_NPF * IB_THREADS;
   return g;
 }
-template <int KK, int S, int MAXU>
-static void launch_image_block(const FusedArgs& a, const ImageBundle& wb, const ImageGeom& g, int B, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_image_kernel<KK, S, MAXU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  mbconv_image_kernel<KK, S, MAXU><<<dim3((unsigned)B), IB_THREADS, g.lds, st>>>(a, wb, g.PW, g.PH, g.NB);
-}
-
 static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const uint8_t* frames, float* boxes, float* scores,
                        float* classes, int* counts, int boff = 0) {
+  if (m->pool_dirty) { const int rc = flush_uploads(m); if (rc) return rc; }
   const OpRec& op = m->ops[s.op];
   const TensorRec& to = m->tensors[op.output];
   auto TP = [&](int t) { return m->tptr[t] + (size_t)boff * m->telems[t]; };
@@ -2518,16 +2418,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         const int NPh = ((TXp - 1) * op.stride + op.k) * ((a.TY - 1) * op.stride + op.k);
         dim3 grid((unsigned)((long)B * a.tiles_x * a.tiles_y), (unsigned)((C + 63) / 64));
         const int lds = NPh * 80;
-#define DW_LAUNCH(KK, S)                                                          \
-  do {                                                                            \
-    if (s.variant == 101) dw_tile_kernel<KK, S, true><<<grid, 256, lds, st>>>(a);  \
-    else dw_tile_kernel<KK, S, false><<<grid, 256, lds, st>>>(a);                  \
-  } while (0)
-        if (op.k == 3 && op.stride == 1) DW_LAUNCH(3, 1);
-        else if (op.k == 3 && op.stride == 2) DW_LAUNCH(3, 2);
-        else if (op.k == 5 && op.stride == 1) DW_LAUNCH(5, 1);
-        else DW_LAUNCH(5, 2);
-#undef DW_LAUNCH
+        launch_dw_tile(a, op.k, op.stride, s.variant == 101, grid, lds, st);
       } else if (s.variant == 0) {  // one output row x 4 columns per lane
         long total = (long)B * to.h * ((to.w + 3) / 4) * (C / 4);
         dim3 grid((unsigned)((total + 255) / 256));
@@ -2595,16 +2486,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const OpRec& dop = m->ops[s.d_op];
       dim3 grid((unsigned)acc);
       const bool mdw = s.variant != 0;
-      if (dop.k == 3 && dop.stride == 1 && s.nbp == 1) {
-        if (mdw) fused_block_multi_kernel<3, 1, 1, false, true><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
-        else fused_block_multi_kernel<3, 1, 1, false, false><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
-      } else if (dop.k == 3 && dop.stride == 1 && s.nbp == 2) {  // BiFPN width 65..128 (Lite1 / Lite2)
-        if (mdw) fused_block_multi_kernel<3, 1, 2, false, true><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
-        else fused_block_multi_kernel<3, 1, 2, false, false><<<grid, 256, s.lds_bytes, st>>>(s.d_multi, mt);
-      } else {
-        set_error("fused_heads_multi: unsupported instantiation (k=%d s=%d nbp=%d)", dop.k, dop.stride, s.nbp);
-        return VBT_ERR_ARG;
-      }
+      { const int rc = launch_fused_multi(s.d_multi, mt, dop.k, dop.stride, s.nbp, mdw, s.lds_bytes, (unsigned)acc, st); if (rc) return rc; }
       break;
     }
     case F_MBCONV:
@@ -2626,17 +2508,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       if (var & 4) {  // one workgroup per image (low-resolution blocks)
         const ImageGeom ig = image_geom(m, s);
         if (!ig.ok) { set_error("fused_mbconv: whole-image variant not applicable"); return VBT_ERR_ARG; }
-#define IB_LAUNCH(KK, S)                                                    \
-  do {                                                                      \
-    if (ig.maxu == 2) launch_image_block<KK, S, 2>(a, s.ib, ig, B, st);           \
-    else if (ig.maxu == 3) launch_image_block<KK, S, 3>(a, s.ib, ig, B, st);      \
-    else launch_image_block<KK, S, 4>(a, s.ib, ig, B, st);                        \
-  } while (0)
-        if (dop.k == 3 && dop.stride == 1) IB_LAUNCH(3, 1);
-        else if (dop.k == 3 && dop.stride == 2) IB_LAUNCH(3, 2);
-        else if (dop.k == 5 && dop.stride == 1) IB_LAUNCH(5, 1);
-        else IB_LAUNCH(5, 2);
-#undef IB_LAUNCH
+        launch_mbconv_image(a, s.ib, dop.k, dop.stride, ig.maxu, ig.PW, ig.PH, ig.NB, ig.lds, B, st);
         break;
       }
       int lds_bytes = s.lds_bytes;
@@ -2665,25 +2537,8 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * (nt3 ? 48 : FB_EST) + 15) & ~15) + 128 * FB_DST;
         grid = dim3((unsigned)((long)B * a.tiles_x * a.tiles_y));
         if (a.OW < 16 || a.OH < 8 || !a.wd64) { set_error("fused_mbconv: the 128-pixel variant needs maps of at least 16 x 8"); return VBT_ERR_ARG; }
-#define FB_P2(KK, S, NBP, KSE)                                                                                      \
-  do {                                                                                                              \
-    if (nt3) fused_block_kernel<KK, S, NBP, true, true, KSE, 3, 2, true><<<grid, 256, lds_bytes, st>>>(a);          \
-    else fused_block_kernel<KK, S, NBP, true, true, KSE, 4, 2, true><<<grid, 256, lds_bytes, st>>>(a);              \
-  } while (0)
-#define FB_P2K(KK, S)                                                                                               \
-  do {                                                                                                              \
-    if (s.nbp == 1 && a.KSe == 1) FB_P2(KK, S, 1, 1);                                                               \
-    else if (s.nbp == 1) FB_P2(KK, S, 1, 2);                                                                        \
-    else if (a.KSe == 1) FB_P2(KK, S, 2, 1);                                                                        \
-    else FB_P2(KK, S, 2, 2);                                                                                        \
-  } while (0)
         if (lds_bytes > 64 * 1024) { set_error("fused_mbconv: 128-pixel tile needs %d bytes of LDS", lds_bytes); return VBT_ERR_ARG; }
-        if (dop.k == 3 && dop.stride == 1) FB_P2K(3, 1);
-        else if (dop.k == 3 && dop.stride == 2) FB_P2K(3, 2);
-        else if (dop.k == 5 && dop.stride == 1) FB_P2K(5, 1);
-        else FB_P2K(5, 2);
-#undef FB_P2K
-#undef FB_P2
+        return launch_fused_block(a, FusedLaunch{dop.k, dop.stride, s.nbp, true, true, nt3, true, true, lds_bytes, grid.x}, st);
         break;
       }
       // 64-pixel tiles of exactly 8 x 8 outputs, K <= 64, <= 128 output channels: depthwise on the 16x16x64 MFMA (DW64)
@@ -2692,45 +2547,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         const int NPh_ = ((8 - 1) * dop.stride + dop.k) * ((8 - 1) * dop.stride + dop.k);
         lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * 48 + 15) & ~15) + 64 * FB_DST;
       }
-#define FB_DW64(KK, S, NBP)                                                                                \
-  do {                                                                                                     \
-    if (nt3 && a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 3, 1, true><<<grid, 256, lds_bytes, st>>>(a);      \
-    else if (nt3) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 2, 3, 1, true><<<grid, 256, lds_bytes, st>>>(a);              \
-    else if (a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 4, 1, true><<<grid, 256, lds_bytes, st>>>(a);       \
-    else fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 2, 4, 1, true><<<grid, 256, lds_bytes, st>>>(a);                       \
-  } while (0)
-#define FB_LAUNCH(KK, S, NBP)                                                                              \
-  do {                                                                                                     \
-    if (dw64) FB_DW64(KK, S, NBP);                                                                          \
-    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 1) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 1, 3><<<grid, 256, lds_bytes, st>>>(a);      \
-    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 2) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 2, 3><<<grid, 256, lds_bytes, st>>>(a); \
-    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 3) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 3, 3><<<grid, 256, lds_bytes, st>>>(a); \
-    else if (ex && mdw && nt3 && NBP <= 2 && a.KSe == 4) fused_block_kernel<KK, S, (NBP <= 2 ? NBP : 1), true, true, 4, 3><<<grid, 256, lds_bytes, st>>>(a); \
-    else if (ex && mdw && a.KSe == 1) fused_block_kernel<KK, S, NBP, true, true, 1><<<grid, 256, lds_bytes, st>>>(a);      \
-    else if (ex && mdw && a.KSe == 2) fused_block_kernel<KK, S, NBP, true, true, 2><<<grid, 256, lds_bytes, st>>>(a); \
-    else if (ex && mdw && a.KSe == 3) fused_block_kernel<KK, S, NBP, true, true, 3><<<grid, 256, lds_bytes, st>>>(a); \
-    else if (ex && mdw && a.KSe == 4) fused_block_kernel<KK, S, NBP, true, true, 4><<<grid, 256, lds_bytes, st>>>(a); \
-    else if (ex && mdw) fused_block_kernel<KK, S, NBP, true, true><<<grid, 256, lds_bytes, st>>>(a);      \
-    else if (ex) fused_block_kernel<KK, S, NBP, true, false><<<grid, 256, lds_bytes, st>>>(a);            \
-    else if (mdw) fused_block_kernel<KK, S, NBP, false, true><<<grid, 256, lds_bytes, st>>>(a);           \
-    else fused_block_kernel<KK, S, NBP, false, false><<<grid, 256, lds_bytes, st>>>(a);                   \
-  } while (0)
-#define FB_NBP(KK, S)                                      \
-  do {                                                     \
-    switch (s.nbp) {                                       \
-      case 1: FB_LAUNCH(KK, S, 1); break;                  \
-      case 2: FB_LAUNCH(KK, S, 2); break;                  \
-      case 3: FB_LAUNCH(KK, S, 3); break;                  \
-      default: FB_LAUNCH(KK, S, 5); break;                 \
-    }                                                      \
-  } while (0)
-      if (dop.k == 3 && dop.stride == 1) FB_NBP(3, 1);
-      else if (dop.k == 3 && dop.stride == 2) FB_NBP(3, 2);
-      else if (dop.k == 5 && dop.stride == 1) FB_NBP(5, 1);
-      else FB_NBP(5, 2);
-#undef FB_NBP
-#undef FB_LAUNCH
-#undef FB_DW64
+      { const int rc = launch_fused_block(a, FusedLaunch{dop.k, dop.stride, s.nbp, ex, mdw, nt3, false, dw64, lds_bytes, grid.x}, st); if (rc) return rc; }
       break;
     }
     case F_CHAIN: {
@@ -2742,26 +2559,15 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         }
         break;
       }
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-      }
-      node_chain_kernel<<<dim3((unsigned)B), NC_THREADS, s.lds_bytes, st>>>(s.d_multi, (int)s.members.size());
+      launch_node_chain(s.d_multi, (int)s.members.size(), B, s.lds_bytes, st);
       break;
     }
     case F_BAND: {
       if (boff != 0) { set_error("fused_sepconv_band: sub-batch streams are not supported (VBT_SUBSTREAMS)"); return VBT_ERR_ARG; }
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_one_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-      }
       MultiTiles mt;
       int acc = 0;
       if (s.members.empty()) {
-        sepconv_band_one_kernel<<<dim3((unsigned)(B * s.band_tiles)), BD_THREADS, s.lds_bytes, st>>>(s.ba);
+        launch_band_one(s.ba, (unsigned)(B * s.band_tiles), s.lds_bytes, st);
         break;
       } else {
         mt.n = (int)s.members.size();
@@ -2771,7 +2577,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         }
       }
       mt.start[mt.n] = acc;
-      sepconv_band_kernel<<<dim3((unsigned)acc), 64 * BD_HEAD_WAVES, s.lds_bytes, st>>>(s.d_band, mt);
+      launch_band_multi(s.d_band, mt, (unsigned)acc, s.lds_bytes, st);
       break;
     }
     case F_EXPDW: {
@@ -2784,29 +2590,14 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
       const int KS64 = (a.Cin + 63) / 64;
       dim3 grid((unsigned)(B * ngroups));
-#define XD_LAUNCH(KK, S)                                                                                             \
-  do {                                                                                                               \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
-    if (KS64 == 2) expdw_image_kernel<KK, S, 2><<<grid, XD_THREADS, s.lds_bytes, st>>>(a);                           \
-    else expdw_image_kernel<KK, S, 3><<<grid, XD_THREADS, s.lds_bytes, st>>>(a);                                     \
-  } while (0)
-      if (dop.k == 3 && dop.stride == 1) XD_LAUNCH(3, 1);
-      else if (dop.k == 5 && dop.stride == 1) XD_LAUNCH(5, 1);
-      else XD_LAUNCH(5, 2);
-#undef XD_LAUNCH
+      launch_expdw(a, dop.k, dop.stride, KS64, grid.x, s.lds_bytes, st);
       break;
     }
     case F_STEMBLK: {
       StemBlockArgs a = s.sb;
       a.frames = frames;
       a.out = out;
-      if (a.rqs.full && a.rqd.full && a.rqp.full) stem_block_kernel<true><<<dim3((unsigned)((long)B * a.tiles_x * a.tiles_y)), 256, 0, st>>>(a);
-      else stem_block_kernel<false><<<dim3((unsigned)((long)B * a.tiles_x * a.tiles_y)), 256, 0, st>>>(a);
+      launch_stem_block(a, a.rqs.full && a.rqd.full && a.rqp.full, (unsigned)((long)B * a.tiles_x * a.tiles_y), st);
       break;
     }
     case F_POST: {
@@ -3031,6 +2822,7 @@ static int enqueue_forward(vbt_model* m, const uint8_t* frames_dev, int B, hipSt
 // Forward = eager launches, or (small batches: the 120-odd launches are host-bound) replay of a captured hipGraph.
 static int forward(vbt_model* m, const uint8_t* frames_dev, int B, hipStream_t st, float* boxes, float* scores, float* classes,
                    int* counts) {
+  if (m->pool_dirty) { const int rc = flush_uploads(m); if (rc) return rc; }   // (never inside a stream capture)
   if (B > m->graph_max_batch || !m->cap_stream) return enqueue_forward(m, frames_dev, B, st, boxes, scores, classes, counts, nullptr);
   vbt_model::GraphKey key{frames_dev, boxes, scores, classes, counts, B};
   auto it = m->graphs.find(key);
@@ -3144,6 +2936,38 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
       std::vector<unsigned char> lut(m->blob.data() + op.aux2_off, m->blob.data() + op.aux2_off + VBT_POST_TABLE_BYTES);
       const float* sv = (const float*)(lut.data() + 6144);
       if (sv[0] != sv[1] || sv[2] != sv[3]) { set_error("post-process: y_scale != x_scale or h_scale != w_scale"); return fail(VBT_ERR_ARG); }
+      {
+        // The stored tables are checked, not trusted: every entry is derived again from the quantisation of the class and
+        // box tensors (XNNPACK's x8 LOGISTIC table in float32 with glibc expf; DEQUANTIZE as one float32 product; the
+        // decode's divisions and exp() in double, detection_postprocess.cc) and a container that differs is refused.
+        const int nl = op.n_inputs / 2;
+        const TensorRec& tc = m->tensors[op.inputs[0]];
+        const TensorRec& tb = m->tensors[op.inputs[nl]];
+        for (int l = 1; l < nl; l++) {   // CONCATENATION: one quantisation for all of its inputs
+          const TensorRec &c2 = m->tensors[op.inputs[l]], &b2 = m->tensors[op.inputs[nl + l]];
+          if (c2.scale != tc.scale || c2.zero_point != tc.zero_point || b2.scale != tb.scale || b2.zero_point != tb.zero_point) {
+            set_error("post-process: head outputs of level %d are quantised differently from level 0", l);
+            return fail(VBT_ERR_ARG);
+          }
+        }
+        const float* st_score = (const float*)lut.data();
+        const float* st_box = st_score + 256;
+        const double* st_dq = (const double*)(lut.data() + 2048);
+        const double* st_ex = st_dq + 256;
+        for (int q = -128; q < 128; q++) {
+          const float x = tc.scale * (float)(q - tc.zero_point);
+          float y = 256.0f / (1.0f + expf(-x));
+          y = y < 0.0f ? 0.0f : (y > 255.0f ? 255.0f : y);
+          const float want_score = (1.0f / 256.0f) * (float)lrintf(y);
+          const float want_box = tb.scale * (float)(q - tb.zero_point);
+          const double want_dq = (double)want_box / (double)sv[0];
+          const double want_ex = exp((double)want_box / (double)sv[2]);
+          if (st_score[q + 128] != want_score || st_box[q + 128] != want_box || st_dq[q + 128] != want_dq || st_ex[q + 128] != want_ex) {
+            set_error("post-process: stored table entry %d differs from the one derived from the tensor scales", q);
+            return fail(VBT_ERR_ARG);
+          }
+        }
+      }
       // device tables: scores re-indexed by rank byte, decode tables, class byte -> rank byte
       std::vector<unsigned char> dev(1024 + 2048 + 2048 + 256, 0);
       const float* score = (const float*)lut.data();
@@ -3192,6 +3016,7 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
     }
   }
   finalize_plan(m);
+  if ((rc = flush_uploads(m)) != VBT_OK) return fail(rc);
   *out = m;
   return VBT_OK;
 }

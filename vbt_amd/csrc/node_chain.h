@@ -12,6 +12,7 @@
 constexpr int NC_WAVES = 16, NC_THREADS = 64 * NC_WAVES;
 constexpr int NC_MAXU = 4;  // project units (16 pixels x 64 channels) per wave: 25 pixel groups x 2 blocks / 16 waves
 
+#ifdef VBT_DEFINE_CHAIN_KERNELS   // not a template: defined by k_image.hip only
 __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs* __restrict__ nodes, int n_nodes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nc_smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -152,3 +153,4 @@ __global__ __launch_bounds__(NC_THREADS) void node_chain_kernel(const FusedArgs*
     __syncthreads();
   }
 }
+#endif  // VBT_DEFINE_CHAIN_KERNELS

@@ -1309,7 +1309,8 @@ int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int3
   if (!t || !best_ids || !n_rows || !n_phases || !overflow || !phases6 || cap < 1) { set_error("bad argument"); return VBT_ERR_ARG; }
   if (!t->finished) { set_error("vbt_tracker_summary before vbt_tracker_finish"); return VBT_ERR_STATE; }
   const int n = t->n_clips;
-  cap = std::min(cap, MAXPH);
+  const int host_cap = cap;     // stride of the caller's phases6 buffer: [n_clips][host_cap][6]
+  cap = std::min(cap, MAXPH);   // phases packed per clip (a clip never holds more than MAXPH)
   const size_t rec = 16 + (size_t)cap * 48, bytes = rec * n;
   if (bytes > t->summary_bytes) {
     if (t->d_summary) (void)hipFree(t->d_summary);
@@ -1328,7 +1329,7 @@ int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int3
     const int* h = (const int*)r;
     best_ids[c] = h[0]; n_rows[c] = h[1]; n_phases[c] = h[2]; overflow[c] = h[3];
     if (h[2] > cap) { set_error("clip %d has %d phases, buffer holds %d", c, h[2], cap); return VBT_ERR_CAPACITY; }
-    memcpy(phases6 + (size_t)c * cap * 6, r + 16, (size_t)h[2] * 48);
+    memcpy(phases6 + (size_t)c * host_cap * 6, r + 16, (size_t)h[2] * 48);
   }
   return VBT_OK;
 }
