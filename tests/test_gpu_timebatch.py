@@ -173,7 +173,7 @@ def test_config2_full_length_clip(model_path):
         two.step_seq(halves[:, t0:t0 + 32].contiguous())
     two.close(cap=512)
     c2, rows2 = two.rows_all()
-    assert np.array_equal(rows2[0, :c2[0]], rrows[0, :c2[0]]) and c2[1] > 1900
+    assert np.array_equal(rows2[0, :c2[0]], rrows[0, :c2[0]]) and c2[1] > 500
 
 
 @pytest.mark.gpu
