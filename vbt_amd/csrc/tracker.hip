@@ -367,13 +367,19 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
     if (lane < T)
       for (int i = 0; i < 4; i++) bx[i] = sh.tbox[lane][i];
     __syncthreads();
-    if (lane < T) {
-      if (isnan_box) atomicAnd(&st.used, ~(1ull << slot));
-      else {
-        int np_ = __popcll(keep & ((1ull << lane) - 1ull));
-        st.order[np_] = slot;
-        for (int i = 0; i < 4; i++) sh.tbox[np_][i] = bx[i];
+    {  // slots of the dropped trackers go back to the pool: one lane clears their bits (no atomics: the state may sit in LDS)
+      unsigned long long nm = nanmask, clr = 0ull;
+      while (nm) {
+        const int l = __ffsll((long long)nm) - 1;
+        nm &= nm - 1;
+        clr |= 1ull << __shfl(slot, l);
       }
+      if (lane == 0) st.used &= ~clr;
+    }
+    if (lane < T && !isnan_box) {
+      int np_ = __popcll(keep & ((1ull << lane) - 1ull));
+      st.order[np_] = slot;
+      for (int i = 0; i < 4; i++) sh.tbox[np_][i] = bx[i];
     }
     T = __popcll(keep);
     if (lane == 0) st.ntrk = T;
@@ -589,11 +595,15 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   unsigned long long km = __ballot(lane < T && keep);
   if (km != (T >= 64 ? ~0ull : ((1ull << T) - 1ull))) {
     __syncthreads();
-    if (lane < T) {
-      if (keep) st.order[__popcll(km & ((1ull << lane) - 1ull))] = myslot;
-      else {
-        atomicAnd(&st.used, ~(1ull << myslot));
+    if (lane < T && keep) st.order[__popcll(km & ((1ull << lane) - 1ull))] = myslot;
+    {
+      unsigned long long dm = ~km & (T >= 64 ? ~0ull : ((1ull << T) - 1ull)), clr = 0ull;
+      while (dm) {
+        const int l = __ffsll((long long)dm) - 1;
+        dm &= dm - 1;
+        clr |= 1ull << __shfl(myslot, l);
       }
+      if (lane == 0) st.used &= ~clr;
     }
     // a finished track competes for the export id (max cumulative distance; ties -> lower id);
     // the few deaths of a frame are serialised
@@ -695,14 +705,40 @@ struct RunMeta {
 struct SeqMeta {
   RunMeta run[META_RUNS];
 };
+// A run of SEQ_LDS_MIN frames or more keeps the clip's tracker state in LDS for the whole walk: the header and the live
+// tracks (a few KB) are copied in once and written back once, and every Kalman / association step in between works on LDS
+// instead of on dependent global round trips (one clip alone: 21 us -> see DESIGN.md per frame).
+constexpr int SEQ_LDS_MIN = 6;
+__device__ inline void copy_words(void* dst, const void* src, int bytes, int lane) {   // 8-byte words, one wavefront
+  unsigned long long* d = (unsigned long long*)dst;
+  const unsigned long long* s_ = (const unsigned long long*)src;
+  for (int i = lane; i < bytes / 8; i += 64) d[i] = s_[i];
+}
+static_assert(sizeof(Trk) % 8 == 0 && offsetof(ClipState, trk) % 8 == 0, "8-byte copy granularity");
 __global__ __launch_bounds__(64) void tracker_seq_kernel(ClipState* states, Row* rows, int rows_cap, const float* boxes,
                                                          const float* scores, const int* counts, SeqMeta meta,
-                                                         float det_threshold, TrackParams p, double q44, double q66) {
+                                                         float det_threshold, TrackParams p, double q44, double q66, int lds_state) {
   __shared__ StepShared sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char seq_dyn[];   // ClipState copy (only when lds_state != 0)
   const int lane = threadIdx.x;
   const RunMeta r = meta.run[blockIdx.x];
   if (r.clip < 0) return;
-  ClipState& st = states[r.clip];
+  ClipState* gst = &states[r.clip];
+  ClipState* st = gst;
+  const bool cached = lds_state != 0 && r.n_frames >= SEQ_LDS_MIN;
+  if (cached) {
+    ClipState* lst = (ClipState*)seq_dyn;
+    copy_words(lst, gst, (int)offsetof(ClipState, trk), lane);
+    __syncthreads();
+    unsigned long long um = lst->used;
+    while (um) {
+      const int sl = __ffsll((long long)um) - 1;
+      um &= um - 1;
+      copy_words(&lst->trk[sl], &gst->trk[sl], (int)sizeof(Trk), lane);
+    }
+    __syncthreads();
+    st = lst;
+  }
   Row* myrows = rows + (size_t)r.clip * rows_cap;
   for (int f = 0; f < r.n_frames; f++) {
     __syncthreads();  // the previous frame's readers of sh.det are done
@@ -710,7 +746,17 @@ __global__ __launch_bounds__(64) void tracker_seq_kernel(ClipState* states, Row*
     __syncthreads();
     if (nd < 0) continue;
     const double frame_time = (double)(r.frame0 + f * r.frame_step) / r.fps;
-    ocsort_step(st, myrows, rows_cap, sh, nd, frame_time, p, q44, q66, lane);
+    ocsort_step(*st, myrows, rows_cap, sh, nd, frame_time, p, q44, q66, lane);
+  }
+  if (cached) {   // write the state back: header + every slot that is live now (slots freed during the walk need no copy)
+    __syncthreads();
+    copy_words(gst, st, (int)offsetof(ClipState, trk), lane);
+    unsigned long long um = st->used;
+    while (um) {
+      const int sl = __ffsll((long long)um) - 1;
+      um &= um - 1;
+      copy_words(&gst->trk[sl], &st->trk[sl], (int)sizeof(Trk), lane);
+    }
   }
 }
 
@@ -1134,8 +1180,19 @@ int vbt_tracker_update_from_detections_seq(vbt_tracker* t, const float* boxes_de
       const vbt_run& r = runs_host[r0 + i];
       meta.run[i] = RunMeta{r.clip, r.slot0, r.slot_stride, r.n_frames, r.frame0, r.frame_step, r.fps};
     }
-    tracker_seq_kernel<<<nb, 64, 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, meta, det_threshold, t->p, t->q44,
-                                          t->q66);
+    int longest = 0;
+    for (int i = 0; i < nb; i++) longest = std::max(longest, meta.run[i].clip >= 0 ? meta.run[i].n_frames : 0);
+    static const bool lds_off = getenv("VBT_SEQ_NO_LDS") != nullptr;
+    const int lds_state = (longest >= SEQ_LDS_MIN && !lds_off) ? 1 : 0;
+    if (lds_state) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tracker_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ClipState));
+        attr_set = true;
+      }
+    }
+    tracker_seq_kernel<<<nb, 64, lds_state ? sizeof(ClipState) : 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, meta,
+                                                                           det_threshold, t->p, t->q44, t->q66, lds_state);
   }
   VBT_HIP_CHECK(hipGetLastError());
   t->finished = false;
