@@ -25,7 +25,6 @@ extern "C" {
 #define VBT_MODEL_NO_GRAPH 64        /* never replay the forward from a captured hipGraph */
 #define VBT_MODEL_NO_HEAD_BATCHING 128 /* one launch per head layer and level instead of one per layer */
 #define VBT_MODEL_NO_STEM_FUSION 256  /* stem conv as its own kernel instead of stem + first SeparableConv fused */
-#define VBT_MODEL_NODE_CHAIN 1024     /* experimental: runs of small BiFPN nodes as ONE launch, one workgroup per image (node_chain.h) */
 #define VBT_MODEL_CHUNK48 2048        /* heuristic plan: 48-channel chunks in fused MBConv blocks whose expanded width allows it */
 #define VBT_MODEL_IMAGE_BLOCKS 512    /* heuristic plan: whole-image MBConv kernel wherever it applies (autotuning decides otherwise) */
 #define VBT_MODEL_TILE128 16384       /* heuristic plan: 128-pixel tiles in the fused MBConv blocks that allow them */

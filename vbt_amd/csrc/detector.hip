@@ -829,10 +829,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
 // ------------------------------------------------------------------------------------------
 // host: model, plan, launches
 // ------------------------------------------------------------------------------------------
-enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_CHAIN, F_EXPDW, F_BAND, F_COUNT };
+enum Family { F_STEM = 0, F_PW, F_DW, F_ADD, F_MAXPOOL, F_RESIZE, F_POST, F_MBCONV, F_SEPCONV, F_NODE, F_MULTI, F_STEMBLK, F_EXPDW, F_BAND, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"stem_conv_mfma_i8", "pw_conv_mfma_i8", "dw_conv_f32acc", "add_requant",
                                            "maxpool3x3s2", "resize_nn", "decode_nms", "fused_mbconv", "fused_sepconv", "fused_bifpn_node", "fused_heads_multi",
-                                           "fused_stem_block", "fused_bifpn_chain", "fused_expand_dw", "fused_sepconv_band"};
+                                           "fused_stem_block", "fused_expand_dw", "fused_sepconv_band"};
 
 struct Step {
   int op;       // index into ops
@@ -1770,7 +1770,6 @@ static Step pw_with_residual(const vbt_model* m, int p_op, int a_op) {
   return s;
 }
 
-static int chain_nodes(vbt_model* m);
 static int fuse_plan(vbt_model* m) {
   const int no = (int)m->ops.size();
   std::vector<int> consumers(m->tensors.size(), 0);
@@ -2016,103 +2015,6 @@ static int fuse_plan(vbt_model* m) {
     int rc = batch_heads(m);
     if (rc) return rc;
   }
-  if (fuse_node) return chain_nodes(m);
-  return VBT_OK;
-}
-
-// Consecutive small BiFPN nodes -> one launch (node_chain.h).  Groups that sit between two chain members but do not
-// depend on the chain (the lateral 1x1 convs of the first cell) are hoisted in front of it.
-static int chain_nodes(vbt_model* m) {
-  // Opt-in (VBT_MODEL_NODE_CHAIN: maps up to 400 pixels, chain chosen without measuring - a plan mode of the parity tests; or
-  // VBT_CHAIN_MAX_HW=<pixels>: offered to the autotuner next to one launch per node).  Measured at B = 64 (round 2): the
-  // 5x5 + 10x10 pair takes 43.5 us as a chain against 5.0 + 6.9 us as two row-band launches - six dependent global round
-  // trips per node on 64 workgroups cost far more than a launch boundary.
-  const bool forced = (m->flags & VBT_MODEL_NODE_CHAIN) != 0;
-  int max_hw = forced ? 400 : 0;
-  if (const char* e = getenv("VBT_CHAIN_MAX_HW")) max_hw = atoi(e);
-  if (max_hw <= 0) return VBT_OK;
-  if (const char* ns = getenv("VBT_SUBSTREAMS")) if (atoi(ns) > 1) return VBT_OK;   // the chain's node list holds whole-batch pointers
-  auto small_node = [&](const Group& g) {
-    const Alt* fap = tile_alt(g, F_NODE);
-    if (!fap) return false;
-    const Step& st = fap->steps[0];
-    const OpRec& d = m->ops[st.d_op];
-    const int HW = st.fa.H * st.fa.W, NB = (st.fa.Cout + 63) / 64;
-    return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && st.fa.OH == st.fa.H && st.fa.OW == st.fa.W && HW <= max_hw &&
-           ((HW + 15) / 16) * NB <= NC_WAVES * NC_MAXU && st.fa.Cin % 4 == 0;
-  };
-  auto outputs_of = [&](const Group& g, std::set<int>& acc) {
-    for (const Step& st : g.alts[0].steps) acc.insert(m->ops[st.op].output);
-  };
-  auto depends_on = [&](const Group& g, const std::set<int>& produced) {
-    for (const Step& st : g.alts[0].steps) {
-      const OpRec& op = m->ops[st.op];
-      for (int i = 0; i < op.n_inputs; i++)
-        if (produced.count(op.inputs[i])) return true;
-    }
-    return false;
-  };
-  std::vector<Group> out;
-  const size_t n = m->groups.size();
-  for (size_t i = 0; i < n;) {
-    if (!small_node(m->groups[i])) { out.push_back(m->groups[i]); i++; continue; }
-    std::vector<size_t> chain{i}, hoisted;
-    std::set<int> produced;
-    outputs_of(m->groups[i], produced);
-    size_t j = i + 1;
-    while (j < n) {
-      if (small_node(m->groups[j])) { chain.push_back(j); outputs_of(m->groups[j], produced); j++; continue; }
-      size_t k = j;  // a run of independent groups followed by another small node?
-      while (k < n && !small_node(m->groups[k]) && !depends_on(m->groups[k], produced)) k++;
-      if (k < n && k > j && small_node(m->groups[k])) {
-        for (size_t h = j; h < k; h++) hoisted.push_back(h);
-        j = k;
-        continue;
-      }
-      break;
-    }
-    for (size_t h : hoisted) out.push_back(m->groups[h]);
-    if (chain.size() < 2) {
-      out.push_back(m->groups[chain[0]]);
-    } else {
-      Group g;
-      Alt each, ch;
-      Step cs;
-      cs.family = F_CHAIN;
-      std::vector<FusedArgs> hargs;
-      for (size_t ci : chain) {
-        const Alt& fa = *tile_alt(m->groups[ci], F_NODE);
-        const Step& ns = fa.steps[0];
-        // "one launch per node" keeps each member's own default realisation (the row-band kernel where it applies)
-        const Alt& own = m->groups[ci].alts[m->groups[ci].chosen];
-        for (const Step& os : own.steps) each.steps.push_back(os);
-        for (int t : own.hidden) each.hidden.push_back(t);
-        for (int t : fa.hidden) ch.hidden.push_back(t);
-        cs.members.push_back(ns);
-        cs.op = ns.op;
-        cs.d_op = ns.d_op;
-        cs.alg_bytes_per_frame += ns.alg_bytes_per_frame;
-        cs.weight_bytes += ns.weight_bytes;
-        cs.macs_per_frame += ns.macs_per_frame;
-        FusedArgs a = ns.fa;
-        for (int q = 0; q < 3; q++) a.src[q] = ns.src_tensor[q] >= 0 ? m->tptr[ns.src_tensor[q]] : nullptr;
-        a.x = nullptr;
-        a.out = m->tptr[m->ops[ns.op].output];
-        hargs.push_back(a);
-        const int Cp = a.nchunks * 64, HW = a.H * a.W;
-        cs.lds_bytes = std::max(cs.lds_bytes, (a.H + 2) * (a.W + 2) * (Cp + 16) + ((HW + 15) / 16) * 16 * FB_DST);
-      }
-      int rc = upload(m, hargs, &cs.d_multi);
-      if (rc) return rc;
-      ch.steps.push_back(cs);
-      g.alts.push_back(each);
-      g.alts.push_back(ch);
-      g.chosen = forced ? 1 : 0;
-      out.push_back(g);
-    }
-    i = j;
-  }
-  m->groups.swap(out);
   return VBT_OK;
 }
 
@@ -2548,18 +2450,6 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         lds_bytes = ((NPh_ * a.T0S + 15) & ~15) + ((NPh_ * 48 + 15) & ~15) + 64 * FB_DST;
       }
       { const int rc = launch_fused_block(a, FusedLaunch{dop.k, dop.stride, s.nbp, ex, mdw, nt3, false, dw64, lds_bytes, grid.x}, st); if (rc) return rc; }
-      break;
-    }
-    case F_CHAIN: {
-      if (boff != 0) {  // sub-batches on side streams: the chain's pointers are those of the whole batch
-        for (const Step& ms : s.members) {
-          int rc = launch_step(m, ms, B, st, frames - (size_t)boff * m->hdr.image_size * m->hdr.image_size * 3, boxes - (size_t)boff * m->hdr.max_detections * 4,
-                               scores - (size_t)boff * m->hdr.max_detections, classes - (size_t)boff * m->hdr.max_detections, counts - boff, boff);
-          if (rc) return rc;
-        }
-        break;
-      }
-      launch_node_chain(s.d_multi, (int)s.members.size(), B, s.lds_bytes, st);
       break;
     }
     case F_BAND: {

@@ -1,6 +1,4 @@
-// One workgroup per image: whole-image MBConv blocks on low-resolution maps (image_block.h) and runs of small BiFPN nodes
-// as one launch (node_chain.h).
-#define VBT_DEFINE_CHAIN_KERNELS 1
+// One workgroup per image: whole-image MBConv blocks on low-resolution maps (image_block.h).
 #include "launchers.h"
 
 namespace vbt {
@@ -28,16 +26,6 @@ int launch_mbconv_image(const FusedArgs& a, const ImageBundle& wb, int k, int st
   else if (k == 5 && stride == 1) IB_LAUNCH(5, 1);
   else IB_LAUNCH(5, 2);
 #undef IB_LAUNCH
-  return VBT_OK;
-}
-
-int launch_node_chain(const FusedArgs* d_nodes, int n_nodes, int B, int lds_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&node_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  node_chain_kernel<<<dim3((unsigned)B), NC_THREADS, lds_bytes, st>>>(d_nodes, n_nodes);
   return VBT_OK;
 }
 

@@ -9,7 +9,6 @@ namespace vbt {
 #include "fused_block.h"   // FusedArgs, MultiTiles, DwTileArgs, FB_* tile constants (+ the kernel templates)
 #include "stem_block.h"    // StemBlockArgs
 #include "image_block.h"   // ImageBundle, IB_*
-#include "node_chain.h"    // NC_*
 #include "expdw_block.h"   // ExpDwArgs, XD_*
 #include "band_block.h"    // BandArgs, BD_*
 
@@ -28,10 +27,9 @@ int launch_fused_block(const FusedArgs& a, const FusedLaunch& L, hipStream_t st)
 int launch_fused_multi(const FusedArgs* d_args, const MultiTiles& mt, int k, int stride, int nbp, bool mdw, int lds_bytes, unsigned grid,
                        hipStream_t st);
 int launch_dw_tile(const DwTileArgs& a, int k, int stride, bool mdw, dim3 grid, int lds_bytes, hipStream_t st);
-// one workgroup per image (image_block.h) and runs of small BiFPN nodes (node_chain.h)
+// one workgroup per image (image_block.h)
 int launch_mbconv_image(const FusedArgs& a, const ImageBundle& wb, int k, int stride, int maxu, int PW, int PH, int NB, int lds_bytes, int B,
                         hipStream_t st);
-int launch_node_chain(const FusedArgs* d_nodes, int n_nodes, int B, int lds_bytes, hipStream_t st);
 // SeparableConv / BiFPN node on row bands (band_block.h): one problem by value, or several problems in one grid
 int launch_band_one(const BandArgs& a, unsigned grid, int lds_bytes, hipStream_t st);
 int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, unsigned grid, int lds_bytes, hipStream_t st);

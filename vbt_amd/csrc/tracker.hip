@@ -328,6 +328,7 @@ __device__ void lap_solve(const double* C, int ld, bool tr, int nr, int nc, int*
 struct StepShared {
   double det[MAXD][6];
   double tbox[MAXT][4];
+  double tq[MAXT][5];  // per tracker: previous-observation centre (x, y), its validity, velocity direction (x, y)
   double iou[MAXD][MAXT];
   double cost[MAXD][MAXT];
   int d2t[MAXD];      // detection -> tracker position paired by the first association (or -1)
@@ -387,7 +388,9 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   __syncthreads();
   const int slot = lane < T ? st.order[lane] : 0;
   // ---- first association: IoU + velocity-direction consistency ----
-  int colsum = 0;
+  // Per-tracker quantities by lane = tracker, then the (detection, tracker) cost entries dealt to the 64 lanes pair by pair:
+  // every entry is the same sequence of double operations as before, but a frame with 20 detections and 3 trackers is one
+  // pass of 60 lanes instead of 20 dependent passes of 3 (sqrt / acos in double dominate the step).
   if (lane < T) {
     Trk& k = st.trk[slot];
     const double* pobs = nullptr;  // k_previous_obs
@@ -400,23 +403,37 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
     }
     double pcx = -1.0, pcy = -1.0, valid = 0.0;
     if (pobs) { pcx = (pobs[0] + pobs[2]) / 2.0; pcy = (pobs[1] + pobs[3]) / 2.0; valid = pobs[4] < 0.0 ? 0.0 : 1.0; }
-    double vy = k.has_vel ? k.vel[0] : 0.0, vx = k.has_vel ? k.vel[1] : 0.0;
+    sh.tq[lane][0] = pcx; sh.tq[lane][1] = pcy; sh.tq[lane][2] = valid;
+    sh.tq[lane][3] = k.has_vel ? k.vel[1] : 0.0;   // vx
+    sh.tq[lane][4] = k.has_vel ? k.vel[0] : 0.0;   // vy
+  }
+  __syncthreads();
+  {
     const double PI = 3.141592653589793;
-    for (int d = 0; d < nd; d++) {
-      const double* dt = sh.det[d];
-      double io = iou_xyxy(dt, sh.tbox[lane]);
-      double dx = (dt[0] + dt[2]) / 2.0 - pcx, dy = (dt[1] + dt[3]) / 2.0 - pcy;
-      double norm = sqrt(dx * dx + dy * dy) + 1e-6;
-      double X = dx / norm, Y = dy / norm;
-      double c = vx * X + vy * Y;
-      c = fmin(fmax(c, -1.0), 1.0);
-      double ang = (PI / 2.0 - fabs(acos(c))) / PI;
-      double ac = ((valid * ang) * p.inertia) * dt[4];
-      sh.iou[d][lane] = io;
-      sh.cost[d][lane] = -(io + ac);
-      colsum += io > p.iou_thr ? 1 : 0;
+    const int npairs = nd * T;
+    for (int p0 = 0; p0 < npairs; p0 += 64) {
+      const int pr = p0 + lane;
+      if (pr < npairs) {
+        const int d = pr / T, t = pr - d * T;
+        const double* dt = sh.det[d];
+        const double pcx = sh.tq[t][0], pcy = sh.tq[t][1], valid = sh.tq[t][2], vx = sh.tq[t][3], vy = sh.tq[t][4];
+        double io = iou_xyxy(dt, sh.tbox[t]);
+        double dx = (dt[0] + dt[2]) / 2.0 - pcx, dy = (dt[1] + dt[3]) / 2.0 - pcy;
+        double norm = sqrt(dx * dx + dy * dy) + 1e-6;
+        double X = dx / norm, Y = dy / norm;
+        double c = vx * X + vy * Y;
+        c = fmin(fmax(c, -1.0), 1.0);
+        double ang = (PI / 2.0 - fabs(acos(c))) / PI;
+        double ac = ((valid * ang) * p.inertia) * dt[4];
+        sh.iou[d][t] = io;
+        sh.cost[d][t] = -(io + ac);
+      }
     }
   }
+  __syncthreads();
+  int colsum = 0;
+  if (lane < T)
+    for (int d = 0; d < nd; d++) colsum += sh.iou[d][lane] > p.iou_thr ? 1 : 0;
   if (lane < MAXD) { sh.d2t[lane] = -1; sh.rej[lane] = 0; sh.taken[lane] = 0; }
   __syncthreads();
   int maxcol = colsum;
@@ -473,15 +490,17 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   bool recovered = false;
   if (nud > 0 && nut > 0) {
     double mx = -1e300;
-    if (lane < nut) {
-      const Trk& k = st.trk[st.order[sh.um_t[lane]]];
-      double lb[4];
-      for (int i = 0; i < 4; i++) lb[i] = k.last_obs[i];
-      for (int i = 0; i < nud; i++) {
+    for (int p0 = 0; p0 < nud * nut; p0 += 64) {   // (unmatched detection, unmatched tracker) pairs dealt to the lanes
+      const int pr = p0 + lane;
+      if (pr < nud * nut) {
+        const int i = pr / nut, j = pr - i * nut;
+        const Trk& k = st.trk[st.order[sh.um_t[j]]];
+        double lb[4];
+        for (int q = 0; q < 4; q++) lb[q] = k.last_obs[q];
         const double* dt = sh.det[sh.um_d[i]];
         double v = p.asso == 1 ? diou_xyxy(dt, lb) : iou_xyxy(dt, lb);
-        sh.iou[i][lane] = v;
-        sh.cost[i][lane] = -v;
+        sh.iou[i][j] = v;
+        sh.cost[i][j] = -v;
         mx = fmax(mx, v);
       }
     }
