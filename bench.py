@@ -245,6 +245,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     cdev = dev if backend == "nccl" else torch.device("cpu")      # where collective buffers live
+    if dist is not None and os.environ.get("VBT_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)   # rehearsal knob (tests): a rank that dies must fail the whole job, not hang it
     if dist is not None:
         ones = torch.ones(1, dtype=torch.float64, device=cdev)   # the collective really spans `world` ranks
         dist.all_reduce(ones)
