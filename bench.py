@@ -515,6 +515,27 @@ def other_configs(torch, dev):
                         "(vbt_tracker_update_from_detections_seq): bound by the sequential tracker walk, not by the detector"}
     guarded("clip1_time_batched", clip1)
 
+    # ---- 64 clips x 4 consecutive frames per detector batch (B = 256): what time-batching adds on top of the clip batch ----
+    def b64x4():
+        n, F, T = 64, 4, 512
+        U = 12 * F
+        fr = torch.from_numpy(make_frames(list(range(n)), 0, U)).to(dev).transpose(0, 1).contiguous()        # [clip][U]
+        pipe = Pipeline(MODEL, n * F, max_frames=T + 8, fps=60.0, tracker_clips=n, rows_per_frame=8)
+
+        def body():
+            pipe.reset()
+            pipe.frame_count = 0
+            for t in range(0, T, F):
+                s = t % U
+                pipe.step_seq(fr[:, s:s + F].contiguous())
+            pipe.close(cap=64)
+            pipe.rows_all()
+        dt = _timed(torch, body)
+        fps = n * T / dt
+        return {"frames_per_s": fps, "ms_per_step": dt / (T // F) * 1e3, "batch": n * F, "clips": n, "frames_per_clip": T, "roofline_frac_8d": roofline_frac_8d(fps, 0, n * F),
+                "note": "frames t..t+3 of 64 clips as one detector batch of 256 (Pipeline.step_seq), OC-SORT walks each clip's 4 frames inside one launch"}
+    guarded("b64x4_time_batched", b64x4)
+
     # ---- config 5's per-GPU shape: the 34-clip corpus (real frame counts / fps) on ONE GPU, time-batched ----
     def corpus():
         meta = json.load(open(CORPUS_META))

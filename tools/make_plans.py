@@ -16,7 +16,7 @@ for f in os.listdir(os.path.join(ROOT, "profiles")):
         shutil.copy(os.path.join(ROOT, "profiles", f), OUT)
 from vbt_amd.interpreter import Interpreter  # noqa: E402
 
-for name, model, batches in (("plan_lite0", "efficientdet_lite0_synth.vbtm", (1, 8, 64)), ("plan_lite2", "efficientdet_lite2_synth.vbtm", (64,))):
+for name, model, batches in (("plan_lite0", "efficientdet_lite0_synth.vbtm", (1, 8, 64, 256)), ("plan_lite2", "efficientdet_lite2_synth.vbtm", (64,))):
     os.environ["VBT_PLAN_FILE"] = os.path.join(OUT, name)
     for b in batches:
         t0 = time.time()

@@ -19,6 +19,17 @@
 
 namespace vbt {
 
+// Phase timers of the OC-SORT step (developer builds only: VBT_EXTRA_CXXFLAGS=-DVBT_TRK_PROF): s_memtime deltas per phase,
+// accumulated by lane 0 of every wavefront; read back with vbt_tracker_prof_read.
+#ifdef VBT_TRK_PROF
+__device__ unsigned long long g_trk_prof[16];
+#define TRK_T0() unsigned long long _tp = __builtin_amdgcn_s_memtime()
+#define TRK_MARK(i) do { unsigned long long _tn = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_trk_prof[i], _tn - _tp); _tp = _tn; } while (0)
+#else
+#define TRK_T0() do {} while (0)
+#define TRK_MARK(i) do {} while (0)
+#endif
+
 constexpr int MAXT = 64;
 constexpr int MAXD = VBT_MAX_DETECTIONS;
 constexpr int MAXPH = 512;  // phases kept per clip
@@ -343,6 +354,7 @@ struct StepShared {
 
 __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& sh, int nd, double time, const TrackParams& p,
                             double q44, double q66, int lane) {
+  TRK_T0();
   if (lane == 0) st.frame_count += 1;
   int T = st.ntrk;
   // ---- predict (KalmanBoxTracker.predict) ----
@@ -387,6 +399,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   }
   __syncthreads();
   const int slot = lane < T ? st.order[lane] : 0;
+  TRK_MARK(0);   // predict
   // ---- first association: IoU + velocity-direction consistency ----
   // Per-tracker quantities by lane = tracker, then the (detection, tracker) cost entries dealt to the 64 lanes pair by pair:
   // every entry is the same sequence of double operations as before, but a frame with 20 detections and 3 trackers is one
@@ -434,6 +447,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   int colsum = 0;
   if (lane < T)
     for (int d = 0; d < nd; d++) colsum += sh.iou[d][lane] > p.iou_thr ? 1 : 0;
+  TRK_MARK(1);   // cost matrix
   if (lane < MAXD) { sh.d2t[lane] = -1; sh.rej[lane] = 0; sh.taken[lane] = 0; }
   __syncthreads();
   int maxcol = colsum;
@@ -462,6 +476,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
       }
     }
   }
+  TRK_MARK(2);   // assignment
   // d2t[d]: tracker position the solver paired with detection d (-1 none); rej[d]: pair rejected (IoU < thr)
   if (lane < T && my_det >= 0) {
     sh.d2t[my_det] = lane;
@@ -485,6 +500,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
     sh.n_um_t = m;
   }
   __syncthreads();
+  TRK_MARK(3);   // matched updates + unmatched lists
   // ---- observation-centric recovery (second association on the last observations) ----
   int nud = sh.n_um_d, nut = sh.n_um_t;
   bool recovered = false;
@@ -535,6 +551,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
     }
   }
   (void)recovered;
+  TRK_MARK(4);   // second association
   // ---- unmatched trackers: update(None) ----
   if (lane < nut && sh.um_t[lane] >= 0) trk_update(st.trk[st.order[sh.um_t[lane]]], nullptr, q44, q66, p.delta_t);
   __syncthreads();
@@ -564,6 +581,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
     }
   }
   __syncthreads();
+  TRK_MARK(5);   // update(None) + births
   // ---- emission (reverse list order) + deletion ----
   T = st.ntrk;
   bool emit = false, keep = true;
@@ -639,6 +657,10 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
     if (lane == 0) st.ntrk = __popcll(km);
   }
   __syncthreads();
+  TRK_MARK(6);   // emission + deletion
+#ifdef VBT_TRK_PROF
+  if (threadIdx.x == 0) { atomicAdd(&g_trk_prof[8], 1ull); atomicAdd(&g_trk_prof[9], (unsigned long long)nd); atomicAdd(&g_trk_prof[10], (unsigned long long)st.ntrk); }
+#endif
 }
 
 // Frames come either as double detections (host-provided, OCSort.update call shape) ...
@@ -1217,6 +1239,18 @@ int vbt_tracker_update_from_detections_seq(vbt_tracker* t, const float* boxes_de
   t->finished = false;
   return VBT_OK;
 }
+
+#ifdef VBT_TRK_PROF
+int vbt_tracker_prof_read(unsigned long long* out16, int reset) {
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  VBT_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trk_prof), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    VBT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trk_prof), z, sizeof(z)));
+  }
+  return VBT_OK;
+}
+#endif
 
 static int fetch_state_header(vbt_tracker* t, int clip, ClipState* hdr_only) {
   // copies only the leading scalars + order + used (not the tracker array)
