@@ -21,7 +21,7 @@ FAM = (("expdw_image", "fused_expand_dw"), ("sepconv_band", "fused_sepconv_band"
        ("mbconv_image", "fused_mbconv"), ("dw_tile", "dw_conv"), ("dw_col", "dw_conv"), ("dw_kernel", "dw_conv"),
        ("pw_a", "pw_conv_mfma_i8"), ("pw_b", "pw_conv_mfma_i8"), ("pw_c", "pw_conv_mfma_i8"), ("stem_kernel", "stem_conv_mfma_i8"),
        ("add_kernel", "add_requant"), ("maxpool", "maxpool3x3s2"), ("resize_kernel", "resize_nn"), ("postprocess", "decode_nms"),
-       ("tracker_from", "ocsort_step"), ("analyze", "rep_analysis"), ("select_gather", "export_select"), ("pack_summary", "close_pack"))
+       ("tracker_from", "ocsort_step"), ("tracker_seq", "ocsort_walk"), ("gather_frames", "frame_gather"), ("analyze", "rep_analysis"), ("select_gather", "export_select"), ("pack_summary", "close_pack"))
 FIRST = "stem_block_kernel"        # first kernel of every forward
 HBM_PEAK = 8.0e12
 SIMDS, CLOCK = 1024, 2.4e9
@@ -79,22 +79,16 @@ def counters(d):
     return out, launches
 
 
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    out_tag = sys.argv[2] if len(sys.argv) > 2 else tag
-    src = f"gpurun_out/{tag}"
-    bench = json.loads(open(f"{src}/bench_default.json").read().strip().splitlines()[-1])
-    k20 = json.loads(open(f"{src}/bench_k20.json").read().strip().splitlines()[-1])
-    json.dump(bench, open(f"profiles/{out_tag}_bench.json", "w"), indent=1)
-    json.dump(k20, open(f"profiles/{out_tag}_bench_k20.json", "w"), indent=1)
-    shutil.copy(one(f"{src}/trace_d3/**/*kernel_stats.csv"), f"profiles/{out_tag}_kernel_stats_depth3.csv")
-    shutil.copy(one(f"{src}/trace_d1/**/*kernel_stats.csv"), f"profiles/{out_tag}_kernel_stats_depth1.csv")
-    a3, nf3, wall3 = steady(f"{src}/trace_d3")
-    a1, nf1, wall1 = steady(f"{src}/trace_d1")
-    cf, lf = counters(f"{src}/pmc_fetch")
-    cw, _ = counters(f"{src}/pmc_write")
-    ca, _ = counters(f"{src}/pmc_sqa")
-    cb, _ = counters(f"{src}/pmc_sqb")
+def summarize(src, pre, out_tag, title, plan, alg_mb_forward, alg_mb_frame, bench=None, k20=None):
+    """src/<pre>trace_d1 ... -> profiles/<out_tag>_{kernel_stats_depth*.csv, summary.md, counters.json}"""
+    shutil.copy(one(f"{src}/{pre}trace_d3/**/*kernel_stats.csv"), f"profiles/{out_tag}_kernel_stats_depth3.csv")
+    shutil.copy(one(f"{src}/{pre}trace_d1/**/*kernel_stats.csv"), f"profiles/{out_tag}_kernel_stats_depth1.csv")
+    a3, nf3, wall3 = steady(f"{src}/{pre}trace_d3")
+    a1, nf1, wall1 = steady(f"{src}/{pre}trace_d1")
+    cf, lf = counters(f"{src}/{pre}pmc_fetch")
+    cw, _ = counters(f"{src}/{pre}pmc_write")
+    ca, _ = counters(f"{src}/{pre}pmc_sqa")
+    cb, _ = counters(f"{src}/{pre}pmc_sqb")
     fams = sorted(a1, key=lambda k: -a1[k][1])
     hbm = {}
     for k in fams:
@@ -103,17 +97,26 @@ def main():
         hbm[k] = (fetch, write)
     us = {k: a1[k][1] / nf1 / 1e3 for k in fams}                  # kernel microseconds per forward (depth 1)
     with open(f"profiles/{out_tag}_summary.md", "w") as f:
-        f.write(f"# {out_tag}: measurement session on one MI355X (64 clips per step, plan = profiles/plan_lite0.b64.f0, tools/profile_session.sh)\n\n")
-        f.write(f"Un-profiled `python bench.py` (defaults: 1000 steps): **{bench['value']:.0f} frames/s end-to-end, {bench['ms_per_step']:.3f} ms/step** "
-                f"(pipeline depth {bench['config'].get('pipeline_depth', 3)}); H2D-inclusive {bench.get('value_h2d_inclusive', 0):.0f} frames/s; "
-                f"detector only {bench['splits']['detect_only']['frames_per_s']:.0f} frames/s; OC-SORT step {bench['splits']['track_only']['us_per_step']:.1f} us per 64 clips.\n")
-        f.write(f"Driver-style `python bench.py --steps 20 --warmup 5`: **{k20['value']:.0f} frames/s, {k20['ms_per_step']:.3f} ms/step** "
-                f"(timed region: enqueue {k20['timed_region_ms']['enqueue']:.2f} ms, clip close incl. pipeline drain {k20['timed_region_ms']['clip_close']:.2f} ms).\n")
+        f.write(f"# {out_tag}: {title} (64 clips per step, plan = {plan}, tools/profile_session.sh)\n\n")
+        if bench is not None:
+            f.write(f"Un-profiled `python bench.py` (defaults: 1000 steps): **{bench['value']:.0f} frames/s end-to-end, {bench['ms_per_step']:.3f} ms/step** "
+                    f"(pipeline depth {bench['config'].get('pipeline_depth', 3)}); H2D-inclusive (pinned host frames in, rows on the host out, same W / K) "
+                    f"{bench.get('value_h2d_inclusive', 0):.0f} frames/s; "
+                    f"detector only {bench['splits']['detect_only']['frames_per_s']:.0f} frames/s; OC-SORT step {bench['splits']['track_only']['us_per_step']:.1f} us per 64 clips.\n")
+            cfgs = bench.get("configs") or {}
+            if cfgs:
+                f.write("Other configurations in the same line: " + "; ".join(f"{k} {v['frames_per_s']:.0f} frames/s ({100 * v['roofline_frac_8d']:.1f} % of the 8d roofline)"
+                                                                              for k, v in cfgs.items() if "frames_per_s" in v) + ".\n")
+        if k20 is not None:
+            f.write(f"Driver-style `python bench.py --steps 20 --warmup 5`: **{k20['value']:.0f} frames/s, {k20['ms_per_step']:.3f} ms/step** "
+                    f"(timed region: enqueue {k20['timed_region_ms']['enqueue']:.2f} ms, clip close incl. pipeline drain {k20['timed_region_ms']['clip_close']:.2f} ms); "
+                    f"cold start (fresh first process, no settle phase) {((k20.get('cold_start') or {}).get('value') or 0):.0f} frames/s; "
+                    f"H2D-inclusive with the same W / K {k20.get('value_h2d_inclusive', 0):.0f} frames/s.\n")
         f.write("Under `rocprofv3 --kernel-trace` dispatches serialise, so the overlap between the forwards in flight is lost while profiling: "
                 f"trace wall per step {wall3:.3f} ms (depth 3) / {wall1:.3f} ms (`VBT_PIPELINE_DEPTH=1`).\n\n")
-        for title, agg, nf, wall in (("depth 1 (one forward at a time)", a1, nf1, wall1), ("depth 3 (bench.py default)", a3, nf3, wall3)):
+        for ttl, agg, nf, wall in (("depth 1 (one forward at a time)", a1, nf1, wall1), ("depth 3 (bench.py default)", a3, nf3, wall3)):
             tot = sum(v[1] for v in agg.values())
-            f.write(f"## kernel time, {title}\n\n| family | launches/step | avg us/launch | ms/step | % GPU time |\n|---|---|---|---|---|\n")
+            f.write(f"## kernel time, {ttl}\n\n| family | launches/step | avg us/launch | ms/step | % GPU time |\n|---|---|---|---|---|\n")
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"| {k} | {v[0]/nf:.1f} | {v[1]/v[0]/1e3:.2f} | {v[1]/nf/1e6:.4f} | {100*v[1]/tot:.1f} |\n")
             f.write(f"\nSum of kernel durations per step: {tot/nf/1e6:.3f} ms; trace wall per step: {wall:.3f} ms.\n\n")
@@ -125,7 +128,7 @@ def main():
             tot_b += fb + wb
             gbs = (fb + wb) / (us[k] * 1e-6) / 1e9 if us[k] else 0
             f.write(f"| {k} | {lf[k]} | {fb/1e6:.1f} | {wb/1e6:.1f} | {(fb+wb)/1e6:.1f} | {us[k]:.1f} | {gbs:.0f} | {100*gbs*1e9/HBM_PEAK:.1f} |\n")
-        f.write(f"\nTotal {tot_b/1e6:.0f} MB per 64-frame forward = {tot_b/64/1e6:.1f} MB/frame, against 2450 MB (38.3 MB/frame, int8) of compulsory traffic "
+        f.write(f"\nTotal {tot_b/1e6:.0f} MB per 64-frame forward = {tot_b/64/1e6:.1f} MB/frame, against {alg_mb_forward:.0f} MB ({alg_mb_frame:.1f} MB/frame, int8) of compulsory traffic "
                 "of the unfused graph (SURVEY.md 8d scaled to 1 byte per element).\n\n")
         f.write("## SQ counters of ONE forward (two `--pmc` passes at depth 1; instruction counts in millions of wave-instructions; wave-state "
                 "counters as a share of SQ_WAVE_CYCLES)\n\n| family | VALU | SALU | LDS | VMEM_RD | MFMA | MFMA busy % of kernel | LDS bank conflict % | waves parked (WAIT_ANY) % | issue stall (WAIT_INST_ANY) % | issuing (ACTIVE_INST_ANY) % |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
@@ -148,21 +151,33 @@ def main():
         pw = "pw_conv_mfma_i8"
         f.write("## The two counter-derived fractions named by the north_star\n\n")
         nstar = {}
-        for k in dw_fams + ["fused_mbconv"]:
+        for k in dw_fams + [x for x in ("fused_mbconv",) if x in us]:
             fb, wb = hbm[k]
             gbs = (fb + wb) / (us[k] * 1e-6)
             nstar[f"{k}_hbm_frac"] = gbs / HBM_PEAK
             f.write(f"* depthwise-bearing family `{k}`: {(fb+wb)/1e6:.1f} MB over {us[k]:.1f} us = {gbs/1e9:.0f} GB/s = **{100*gbs/HBM_PEAK:.1f} % of the 8 TB/s HBM peak**\n")
         if pw in us:
             nstar["pw_mfma_util"] = derived[pw]["mfma_busy_frac"]
-            macs = None
             f.write(f"* pointwise convs `{pw}` (16x16x64 int8 MFMA): SQ_VALU_MFMA_BUSY_CYCLES {cb[pw].get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1e6:.1f} M over "
                     f"{us[pw]:.1f} us x 2.4 GHz x 1024 SIMDs = **{100*derived[pw]['mfma_busy_frac']:.1f} % MFMA utilisation**\n")
-    json.dump({"plan": "profiles/plan_lite0.b64.f0", "batch": 64, "session": tag,
+    json.dump({"plan": plan, "batch": 64, "session": out_tag,
                "families": {k: {"launches": lf[k], "hbm_bytes_per_launch": (hbm[k][0] + hbm[k][1]) / lf[k], "kernel_us_per_forward": us[k]} for k in fams if lf[k]},
                "derived": {"per_family": derived, "north_star": nstar}},
               open(f"profiles/{out_tag}_counters.json", "w"), indent=1)
     print(open(f"profiles/{out_tag}_summary.md").read())
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    out_tag = sys.argv[2] if len(sys.argv) > 2 else tag
+    src = f"gpurun_out/{tag}"
+    bench = json.loads(open(f"{src}/bench_default.json").read().strip().splitlines()[-1])
+    k20 = json.loads(open(f"{src}/bench_k20.json").read().strip().splitlines()[-1])
+    json.dump(bench, open(f"profiles/{out_tag}_bench.json", "w"), indent=1)
+    json.dump(k20, open(f"profiles/{out_tag}_bench_k20.json", "w"), indent=1)
+    summarize(src, "", out_tag, "measurement session on one MI355X, EfficientDet-Lite0 320x320", "profiles/plan_lite0.b64.f0", 2450.0, 38.3, bench, k20)
+    if glob.glob(f"{src}/lite2_trace_d1"):                       # BASELINE config 4: EfficientDet-Lite2 448x448
+        summarize(src, "lite2_", out_tag + "_lite2", "EfficientDet-Lite2 448x448 on one MI355X", "profiles/plan_lite2.b64.f0", 64 * 115.645, 115.6)
 
 
 if __name__ == "__main__":
