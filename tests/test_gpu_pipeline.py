@@ -350,7 +350,7 @@ def test_busy_streams_sit_on_distinct_hardware_queues(model_path):
     import ctypes
     from vbt_amd import _lib
     from vbt_amd.track import Pipeline
-    pipe = Pipeline(model_path, 2, max_frames=4, fps=60.0)
+    pipe = Pipeline(model_path, 2, max_frames=4, fps=60.0, depth=3)   # three forwards + the copy stream = the four hardware queues
     L = _lib.lib()
 
     def shared(a, b):
