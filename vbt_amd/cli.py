@@ -34,26 +34,16 @@ def main():
 @click.option("--df_dir", default=None, show_default=True, help="Directory for exporting the dataframes.")
 @click.option("--fps", default=30.0, show_default=True, type=float, help="Frame rate of the source (cap.get(CAP_PROP_FPS) in the reference).")
 @click.option("--frame_stride", default=1, show_default=True, type=int, help="16 reproduces `frame_count %% 16` of reference track.py:166.")
-def track(src, model, detection_treshold, df_dir, fps, frame_stride):
-    import torch
-    from .track import Pipeline, export_dataframe
+@click.option("--time_batch", default=64, show_default=True, type=int, help="Consecutive frames of the clip per detector batch (1 = one frame per step).")
+def track(src, model, detection_treshold, df_dir, fps, frame_stride, time_batch):
+    from .track import export_dataframe, track_frames
     for s in src:
         if not os.path.isfile(s):
             raise FileNotFoundError(s)                                   # reference track.py:89-90
         frames = np.load(s, mmap_mode="r")
         if frames.ndim != 4 or frames.shape[3] != 3 or frames.dtype != np.uint8:
             raise click.ClickException(f"{s}: expected uint8 [T,H,W,3], got {frames.dtype} {frames.shape}")
-        T, H, W = frames.shape[:3]
-        pipe = Pipeline(model, 1, max_frames=T, fps=fps, detection_treshold=detection_treshold, depth=2, rows_per_frame=25)
-        st = torch.cuda.current_stream().cuda_stream
-        for t in range(T):
-            if frame_stride > 1 and (t + 1) % frame_stride:
-                pipe.skip_frames(1)                                      # skipped frames still advance time (track.py:161-169)
-                continue
-            fd = torch.from_numpy(np.ascontiguousarray(frames[t:t + 1])).cuda()
-            pipe.step(fd, st, src_hw=(H, W))
-        pipe.finish(st)
-        data = pipe.rows(0)
+        data = track_frames(frames, model, fps=fps, detection_treshold=detection_treshold, frame_stride=frame_stride, time_batch=time_batch)
         if not data["id"]:
             click.echo(f"{s}: no tracked rows")
             continue

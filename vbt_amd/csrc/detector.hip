@@ -1662,9 +1662,38 @@ static int make_stem_block(vbt_model* m, int si, Step* out) {
 }
 
 // ---- expand + depthwise on whole images (expdw_block.h) ----
-static int expdw_lds(const ExpDwArgs& a) {
-  const int HW = a.H * a.W, NPGo = (a.OH * a.OW + 15) / 16;
-  return ((HW * a.T0S + 15) & ~15) + a.PH * a.PW * XD_EST + NPGo * 16 * XD_EST;
+// LDS of the whole-image / row-band expand + depthwise kernel for `nbands` bands: T0 (input rows of the tallest band) | E | D
+struct ExpDwGeom { int nbands, brows, t0_bytes, e_bytes, d_bytes; };
+static ExpDwGeom expdw_geom(int H, int W, int OH, int OW, int k, int stride, int pad_t, int pad_l, int T0S, int nbands) {
+  ExpDwGeom g;
+  g.nbands = nbands;
+  g.brows = (OH + nbands - 1) / nbands;
+  g.nbands = (OH + g.brows - 1) / g.brows;
+  const int PW = std::max((OW - 1) * stride + k, pad_l + W);
+  int in_rows = 0;
+  for (int b = 0; b < g.nbands; b++) {
+    const int oy0 = b * g.brows, oy1 = std::min(oy0 + g.brows, OH);
+    const int PHb = (oy1 - oy0 - 1) * stride + k;
+    const int lo = std::max(oy0 * stride - pad_t, 0), hi = std::min(oy0 * stride - pad_t + PHb, H);
+    in_rows = std::max(in_rows, hi - lo);
+  }
+  const int PHmax = (g.brows - 1) * stride + k;
+  g.t0_bytes = (in_rows * W * T0S + 15) & ~15;
+  g.e_bytes = PHmax * PW * XD_EST;
+  g.d_bytes = ((g.brows * OW + 15) / 16) * 16 * XD_EST;
+  return g;
+}
+// whole image when the map has at most 400 pixels and fits (every block of Lite0: the round-2 plan is unchanged); otherwise the
+// fewest bands whose workgroup stays below VBT_XD_BAND_LDS bytes (default 96 KB: one and a half workgroups' worth of a CU)
+static ExpDwGeom expdw_choose(int H, int W, int OH, int OW, int k, int stride, int pad_t, int pad_l, int T0S) {
+  static const int budget = getenv("VBT_XD_BAND_LDS") ? atoi(getenv("VBT_XD_BAND_LDS")) : 96 * 1024;
+  ExpDwGeom g = expdw_geom(H, W, OH, OW, k, stride, pad_t, pad_l, T0S, 1);
+  if (H * W <= 400 && OH * OW <= 400 && g.t0_bytes + g.e_bytes + g.d_bytes <= 160 * 1024) return g;
+  for (int nb = 2; nb <= OH; nb++) {
+    g = expdw_geom(H, W, OH, OW, k, stride, pad_t, pad_l, T0S, nb);
+    if (g.t0_bytes + g.e_bytes + g.d_bytes <= budget) return g;
+  }
+  return g;
 }
 static bool expdw_ok(const vbt_model* m, int e_op, int d_op) {
   const OpRec& e = m->ops[e_op];
@@ -1673,7 +1702,9 @@ static bool expdw_ok(const vbt_model* m, int e_op, int d_op) {
   const TensorRec& tout = m->tensors[d.output];
   const int KS64 = (tin.c + 63) / 64;
   const bool shape = (d.k == 3 && d.stride == 1) || (d.k == 5 && (d.stride == 1 || d.stride == 2));
-  return shape && tin.h * tin.w <= 400 && tout.h * tout.w <= 400 && tin.c % 16 == 0 && tout.c % 16 == 0 && KS64 >= 2 && KS64 <= 3;
+  if (!(shape && tin.h * tin.w <= 1024 && tin.c % 8 == 0 && tout.c % 16 == 0 && KS64 >= 2 && KS64 <= 4)) return false;
+  const ExpDwGeom g = expdw_choose(tin.h, tin.w, tout.h, tout.w, d.k, d.stride, d.pad_t, d.pad_l, ((tin.c + 15) / 16 | 1) * 16);
+  return g.t0_bytes + g.e_bytes + g.d_bytes <= 160 * 1024;
 }
 static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
   const OpRec& eop = m->ops[e_op];
@@ -1700,6 +1731,8 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
   a.T0S = ((tin.c + 15) / 16 | 1) * 16;
   a.nchunks = nch;
   a.cpw = 1;
+  const ExpDwGeom geo = expdw_choose(a.H, a.W, a.OH, a.OW, dop.k, dop.stride, a.pad_t, a.pad_l, a.T0S);
+  a.nbands = geo.nbands; a.brows = geo.brows; a.t0_bytes = geo.t0_bytes; a.e_bytes = geo.e_bytes;
   const int8_t* we = (const int8_t*)(m->blob.data() + eop.w_off);
   const int32_t* bqe = (const int32_t*)(m->blob.data() + eop.b_off);
   const float* mue = (const float*)(m->blob.data() + eop.m_off);
@@ -1749,7 +1782,7 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
   a.rqe = make_rq(te.zero_point, eop.act_min, eop.act_max);
   a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max);
   a.zeb = (unsigned)(te.zero_point & 255) * 0x01010101u;
-  s.lds_bytes = expdw_lds(a);
+  s.lds_bytes = geo.t0_bytes + geo.e_bytes + geo.d_bytes;
   for (int oi : {e_op, d_op}) {
     s.alg_bytes_per_frame += m->op_steps[oi].alg_bytes_per_frame;
     s.weight_bytes += m->op_steps[oi].weight_bytes;
@@ -2476,10 +2509,10 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const OpRec& dop = m->ops[s.d_op];
       a.x = TP(eop.inputs[0]);
       a.out = out;
-      a.cpw = s.variant > 0 ? s.variant : std::max(1, (a.nchunks * B + 511) / 512);   // default: about two workgroups per CU
+      a.cpw = s.variant > 0 ? s.variant : std::max(1, (a.nchunks * a.nbands * B + 511) / 512);   // default: about two workgroups per CU
       const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
       const int KS64 = (a.Cin + 63) / 64;
-      dim3 grid((unsigned)(B * ngroups));
+      dim3 grid((unsigned)(B * ngroups * a.nbands));
       launch_expdw(a, dop.k, dop.stride, KS64, grid.x, s.lds_bytes, st);
       break;
     }

@@ -33,10 +33,13 @@ struct ExpDwArgs {
   const int8_t* x;   // [B][H][W][Cin]
   int8_t* out;       // [B][OH][OW][Ce]: the graph's depthwise output tensor
   int H, W, Cin, OH, OW, Ce;
-  int PW, PH;        // bordered E image
+  int PW, PH;        // bordered E image (PH: of the tallest band)
+  int t0_bytes, e_bytes;   // LDS bytes of T0 / E (sized for the tallest band)
   int pad_t, pad_l;
   int T0S;           // odd multiple of 16 bytes >= Cin
   int nchunks, cpw;  // 64-channel chunks in all / per workgroup
+  int nbands, brows; // row bands per image (1: the whole image) / output rows per band: maps of more than 400 pixels (Lite1 / Lite2)
+                     // do not fit LDS as a whole - a workgroup then owns `brows` output rows and expands the input rows they need
   const v4i* we;     // expand weights [chunk][ks][t][lane] x 16 B: row i of tile t = channel 64c + 16t + i, k = 64ks + 16g + j
   const int* be;     // bias with the input zero point folded, padded to 64 * nchunks
   const float* me;
@@ -54,26 +57,43 @@ __global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
   constexpr int KT = (KK * KK + 3) / 4;   // depthwise MFMAs per unit: four taps each
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int ngroups = fdiv_small(a.nchunks + a.cpw - 1, frcp(a.cpw));
-  const long b = fdiv_small((int)blockIdx.x, frcp(ngroups));
-  const int grp = blockIdx.x - (int)b * ngroups;
-  const int HW = a.H * a.W, OHW = a.OH * a.OW;
+  const int per_image = ngroups * a.nbands;
+  const long b = fdiv_small((int)blockIdx.x, frcp(per_image));
+  const int rem = blockIdx.x - (int)b * per_image;
+  const int band = fdiv_small(rem, frcp(ngroups));
+  const int grp = rem - band * ngroups;
+  // band geometry: output rows [oy0, oy1), the rows of the padded expanded image they read, the input rows behind those
+  const int oy0 = band * a.brows, oy1 = min(oy0 + a.brows, a.OH);
+  const int PHb = (oy1 - oy0 - 1) * S + KK;                        // rows of this band's E image
+  const int iy_lo = max(oy0 * S - a.pad_t, 0), iy_hi = min(oy0 * S - a.pad_t + PHb, a.H);
+  const int erow0 = iy_lo + a.pad_t - oy0 * S;                     // E row of input row iy_lo
+  const int HW = (iy_hi - iy_lo) * a.W, OHW = (oy1 - oy0) * a.OW;  // pixels of the band: input / output
   const int NPGi = (HW + 15) >> 4, NPGo = (OHW + 15) >> 4;
   unsigned char* T0 = xd_smem;
-  unsigned char* E = T0 + ((HW * a.T0S + 15) & ~15);
-  unsigned char* D = E + a.PH * a.PW * XD_EST;
+  unsigned char* E = T0 + a.t0_bytes;
+  unsigned char* D = E + a.e_bytes;
   const float rcp_w = frcp(a.W), rcp_ow = frcp(a.OW);
 
-  // ---- input image -> T0 (16-byte granules; Cin % 16 == 0), E <- zero point everywhere (the border keeps it) ----
+  // ---- input rows -> T0 (16-byte granules, 8-byte ones when Cin % 16 != 0), E <- zero point everywhere (border and rows outside the image keep it) ----
   {
-    const int ng = a.Cin >> 4;
-    const float rcp_ng = frcp(ng);
-    const int8_t* xb = a.x + b * (long)HW * a.Cin;
-    for (int i = tid; i < HW * ng; i += XD_THREADS) {
-      const int p = fdiv_small(i, rcp_ng), sg = i - p * ng;
-      *(uint4*)(T0 + p * a.T0S + 16 * sg) = *(const uint4*)(xb + p * a.Cin + 16 * sg);
+    const int8_t* xb = a.x + (b * (long)a.H + iy_lo) * a.W * a.Cin;
+    if ((a.Cin & 15) == 0) {
+      const int ng = a.Cin >> 4;
+      const float rcp_ng = frcp(ng);
+      for (int i = tid; i < HW * ng; i += XD_THREADS) {
+        const int p = fdiv_small(i, rcp_ng), sg = i - p * ng;
+        *(uint4*)(T0 + p * a.T0S + 16 * sg) = *(const uint4*)(xb + p * a.Cin + 16 * sg);
+      }
+    } else {   // 88 / 120 input channels (Lite2): 8-byte granules (Cin % 8 == 0)
+      const int ng = a.Cin >> 3;
+      const float rcp_ng = frcp(ng);
+      for (int i = tid; i < HW * ng; i += XD_THREADS) {
+        const int p = fdiv_small(i, rcp_ng), sg = i - p * ng;
+        *(uint2*)(T0 + p * a.T0S + 8 * sg) = *(const uint2*)(xb + p * a.Cin + 8 * sg);
+      }
     }
     const uint4 z4 = make_uint4(a.zeb, a.zeb, a.zeb, a.zeb);
-    for (int i = tid; i < a.PH * a.PW * (XD_EST / 16); i += XD_THREADS) *(uint4*)(E + 16 * i) = z4;
+    for (int i = tid; i < PHb * a.PW * (XD_EST / 16); i += XD_THREADS) *(uint4*)(E + 16 * i) = z4;
   }
   const int tq = wave & 3;   // this wave's 16-channel tile of the chunk, in both stages
   // depthwise lane geometry: lane (r, g) reads, for MFMA m, the 16 channels of tile tq at input pixel
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
       for (int ks = 0; ks < KS64; ks++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ew[ks], *(const v4i*)(brow + 64 * ks), acc, 0, 0, 0);
       if (p < HW) {
         const int py = fdiv_small(p, rcp_w), px = p - py * a.W;
-        *(unsigned*)(E + ((py + a.pad_t) * a.PW + px + a.pad_l) * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, em, a.rqe);
+        *(unsigned*)(E + ((py + erow0) * a.PW + px + a.pad_l) * XD_EST + 16 * tq + 4 * g) = rq_pack_b(acc, em, a.rqe);
       }
     }
     __syncthreads();   // E complete; the previous chunk's D has been copied out (that copy precedes this barrier)
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
     {
       const int nv = min(64, a.Ce - 64 * c) >> 4;   // 16-byte parts of this chunk (Ce % 16 == 0)
       const float rcp_nv = frcp(nv);
-      int8_t* ob = a.out + b * (long)OHW * a.Ce + 64 * c;
+      int8_t* ob = a.out + (b * (long)a.OH + oy0) * a.OW * a.Ce + 64 * c;
       for (int i = tid; i < OHW * nv; i += XD_THREADS) {
         const int slot = fdiv_small(i, rcp_nv), part = i - slot * nv;
         *(uint4*)(ob + slot * a.Ce + 16 * part) = *(const uint4*)(D + slot * XD_EST + 16 * part);

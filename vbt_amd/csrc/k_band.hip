@@ -34,10 +34,12 @@ int launch_expdw(const ExpDwArgs& a, int k, int stride, int KS64, unsigned grid_
     if (!attr_set) {                                                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       attr_set = true;                                                                                               \
     }                                                                                                                \
     if (KS64 == 2) expdw_image_kernel<KK, S, 2><<<grid, XD_THREADS, lds_bytes, st>>>(a);                             \
-    else expdw_image_kernel<KK, S, 3><<<grid, XD_THREADS, lds_bytes, st>>>(a);                                       \
+    else if (KS64 == 3) expdw_image_kernel<KK, S, 3><<<grid, XD_THREADS, lds_bytes, st>>>(a);                        \
+    else expdw_image_kernel<KK, S, 4><<<grid, XD_THREADS, lds_bytes, st>>>(a);                                       \
   } while (0)
   if (k == 3 && stride == 1) XD_LAUNCH(3, 1);
   else if (k == 5 && stride == 1) XD_LAUNCH(5, 1);

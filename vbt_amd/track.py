@@ -60,6 +60,30 @@ def track(src, interpreter, detection_treshold=0.5, display_image_height=720, vi
     return data
 
 
+def track_frames(frames, model_path, fps=30.0, detection_treshold=0.5, frame_stride=1, time_batch=64, device=0):
+    """The whole clip loop of reference track.py:129-260 on the time-batched device path: `time_batch` consecutive (kept)
+    frames of the clip per detector batch, OC-SORT walking each batch in frame order on the device, nothing but the finished
+    rows coming back.  frames: uint8 [T,H,W,3] RGB (numpy array or memmap; any resolution - resized on the GPU like
+    odt.py:10-19).  frame_stride = the `frame_count % 16` of track.py:166: frames whose 1-based number is not a multiple are
+    read and dropped, they only advance the clip time.  Returns the reference's dict of lists (track.py:144-145)."""
+    import torch
+    T, H, W = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    stride = max(int(frame_stride), 1)
+    kept = np.arange(stride - 1, T, stride)                          # 0-based indices of the frames that are processed
+    F = max(1, min(int(time_batch), max(len(kept), 1)))
+    pipe = Pipeline(model_path, F, max_frames=max(len(kept), 1), fps=fps, detection_treshold=detection_treshold, device=device,
+                    rows_per_frame=25, tracker_clips=1)
+    size = int(pipe.interpreter.get_input_details()[0]["shape"][1])
+    src_hw = None if (H, W) == (size, size) else (H, W)
+    for i0 in range(0, len(kept), F):
+        idx = kept[i0:i0 + F]
+        chunk = frames[idx[0]:idx[-1] + 1:stride] if stride > 1 else frames[idx[0]:idx[-1] + 1]
+        fd = torch.from_numpy(np.ascontiguousarray(chunk)).to(f"cuda:{device}", non_blocking=False)
+        pipe.step_runs(fd, [(0, 0, len(idx), int(idx[0]) + 1, stride)], src_hw=src_hw)
+    pipe.finish()
+    return pipe.rows(0)
+
+
 def export_dataframe(data, src_name, model_path, df_dir=None, write=True):
     """reference track.py:103-126: sort by (id,time) keeping the original row labels, pick the id with
     the largest cumulative path length, name the file f'{video}_id{id}_{model}.pkl.gz'."""
