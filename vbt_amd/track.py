@@ -233,7 +233,8 @@ class Pipeline:
                     return False
             return True
 
-        busy = [("det", k) for k in range(self.depth)] + [("copy", 0)] + ([] if self._trk_inline else [("trk", 0)])
+        # (four hardware queues: with four forwards in flight the copy stream has to share one, which costs a small batch nothing)
+        busy = [("det", k) for k in range(self.depth)] + ([("copy", 0)] if self.depth < 4 else []) + ([] if self._trk_inline else [("trk", 0)])
         placed, budget, warned = [], 12, False                # at most 12 replacement streams per pipeline
         for kind, k in busy:
             cur = self._det_streams[k] if kind == "det" else (self._copy_stream if kind == "copy" else self._trk_stream)
