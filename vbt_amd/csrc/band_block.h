@@ -1,5 +1,5 @@
-// SeparableConv (depthwise 3x3 / 1 SAME -> pointwise) on ROW BANDS of a 64-channel map: the BiFPN nodes and the box / class
-// head layers of EfficientDet-Lite0 (BiFPN width 64).  Optional BiFPN node input: the band is the sum (+ReLU6) of two or
+// SeparableConv (depthwise 3x3 / 1 SAME -> pointwise) on ROW BANDS of a C-channel map (C = the BiFPN width: 64 / 88 / 112 for
+// EfficientDet-Lite0 / 1 / 2): the BiFPN nodes and the box / class head layers.  Optional BiFPN node input: the band is the sum (+ReLU6) of two or
 // three resampled sources (binary integer ADDs, node_sum4 of fused_block.h).
 //
 // Why not the 64-pixel tile kernel (fused_block.h) here: on these layers a tile does ~120 wave-instructions of
@@ -8,9 +8,9 @@
 // per-workgroup costs are paid once per band, the halo is two rows, the projection weights / biases are staged in LDS
 // once, and the projection is dealt in (pixel group, 16-channel tile) units, so a 9- or 36-channel head output costs a
 // quarter / three quarters of a 64-channel one instead of the same.
-// LDS:  T0 [(rows+2)*(W+2)][80]  input band with its 1-pixel border (zero point outside the image)
-//       D  [rows*W (16-padded)][80]  depthwise output
-//       WP [4][64] x 16 B  projection weights, natural channel order | bias int[64] | mult float[64]
+// LDS:  T0 [(rows+2)*(W+2)][CS]  input band with its 1-pixel border (zero point outside the image); CS = odd multiple of 16 >= C
+//       D  [rows*W (16-padded)][CS]  depthwise output
+//       WP [NT][KS][64] x 16 B  projection weights, natural channel order | bias int[16 NT] | mult float[16 NT]
 // 16 wavefronts; both stages on the 16x16x64 int8 MFMA (depthwise as a diagonal-embedded matrix product, four taps per
 // instruction: three instructions for 3x3).  Arithmetic identical to the per-op kernels.
 #pragma once
@@ -19,19 +19,21 @@
 #define VBT_BD_WAVES 16
 #endif
 constexpr int BD_WAVES = VBT_BD_WAVES, BD_THREADS = 64 * BD_WAVES;
-constexpr int BD_ST = 80;   // bytes per pixel row of T0 and D
+constexpr int BD_WP_TAIL = 1024;   // bias (512 B) | multipliers (512 B) behind the projection weights in LDS
 
 struct BandArgs {
-  const int8_t* x;   // [B][H][W][64] (plain input; unused when n_src > 0)
+  const int8_t* x;   // [B][H][W][C] (plain input; unused when n_src > 0)
   int8_t* out;       // [B][H][W][Cout]
   int H, W, Cout, rows, nbands;
+  int C, CS;         // input channels (% 8 == 0) / bytes per pixel row of T0 and D: odd multiple of 16 >= C
+  int NCG, KS;       // 16-channel groups of the depthwise: ceil(C / 16) / projection K-steps of 64: ceil(C / 64)
   unsigned zx4;      // zero point of the depthwise input x4
   const v4i* wd;     // [cg][m][lane] x 16 B: row i = channel 16cg + i, k = 16g + j -> tap 4m + g, diagonal j == i
-  const int* bd;     // bias with the input zero point folded (64)
+  const int* bd;     // bias with the input zero point folded (16 NCG)
   const float* md;
   Rq rqd;
-  const v4i* wp;     // [t][lane] x 16 B: row i = output channel 16t + i, k = 16g + j (K = 64: one MFMA step)
-  const int* bp;     // bias with the depthwise output's zero point folded, padded to 64
+  const v4i* wp;     // [t][ks][lane] x 16 B: row i = output channel 16t + i, k = 64ks + 16g + j
+  const int* bp;     // bias with the depthwise output's zero point folded, padded to 64-channel blocks
   const float* mp;
   Rq rqp;
   // BiFPN node: see FusedArgs
@@ -42,13 +44,14 @@ struct BandArgs {
 };
 
 __device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long b, int iy, int ix, int cd, bool up2) {
-  const int8_t* sb = a.src[j] + b * (long)a.sh[j] * a.sw[j] * 64 + 4 * cd;
-  if (a.smode[j] == 0) return *(const unsigned*)(sb + (iy * a.sw[j] + ix) * 64);
+  const int C = a.C;
+  const int8_t* sb = a.src[j] + b * (long)a.sh[j] * a.sw[j] * C + 4 * cd;
+  if (a.smode[j] == 0) return *(const unsigned*)(sb + (iy * a.sw[j] + ix) * C);
   if (a.smode[j] == 1) {
     int yy, xx;
     if (up2) { yy = iy >> 1; xx = ix >> 1; }
     else { yy = (iy * a.sh[j]) / a.H; xx = (ix * a.sw[j]) / a.W; }
-    return *(const unsigned*)(sb + (yy * a.sw[j] + xx) * 64);
+    return *(const unsigned*)(sb + (yy * a.sw[j] + xx) * C);
   }
   unsigned lo = 0u, hi = 0u;   // 3x3/2 max pool read in place on the u8 image of the bytes (out-of-map taps = -128)
 #pragma unroll
@@ -57,7 +60,7 @@ __device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long 
 #pragma unroll
     for (int kx = 0; kx < 3; kx++) {
       const int xx = ix * 2 + kx - a.spl[j], xc = min(max(xx, 0), a.sw[j] - 1);
-      unsigned t = *(const unsigned*)(sb + (yc * a.sw[j] + xc) * 64);
+      unsigned t = *(const unsigned*)(sb + (yc * a.sw[j] + xc) * C);
       t = (yy == yc && xx == xc) ? (t ^ 0x80808080u) : 0u;
       lo = pk_max_u16(lo, t & 0x00FF00FFu);
       hi = pk_max_u16(hi, (t >> 8) & 0x00FF00FFu);
@@ -77,24 +80,28 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int y0 = band * a.rows, nr = min(a.rows, a.H - y0);
   const int PW = a.W + 2, NPh = (nr + 2) * PW, NPo = nr * a.W, NPG = (NPo + 15) >> 4;
+  const int C = a.C, CS = a.CS;
   unsigned char* T0 = bd_smem;
-  unsigned char* D = T0 + (a.rows + 2) * PW * BD_ST;
-  unsigned char* WP = D + (((a.rows * a.W + 15) >> 4) << 4) * BD_ST;   // 4 KB weights | 256 B bias | 256 B mult
-  const int NT = (a.Cout + 15) >> 4;
+  unsigned char* D = T0 + (a.rows + 2) * PW * CS;
+  unsigned char* WP = D + (((a.rows * a.W + 15) >> 4) << 4) * CS;   // NT x KS KB of weights | 512 B bias | 512 B mult
+  const int NT = (a.Cout + 15) >> 4, KS = a.KS;
+  unsigned char* WB = WP + NT * KS * 1024;
 
   // ---- stage L: band + border -> T0; projection weights / bias / multipliers -> LDS ----
-  for (int i = tid; i < NT * 64; i += nthreads) *(v4i*)(WP + 16 * i) = a.wp[i];
-  if (tid < 16) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.bp + 16 * tid);
-  else if (tid < 32) *(uint4*)(WP + 4096 + 16 * tid) = *(const uint4*)((const unsigned char*)a.mp + 16 * (tid - 16));
+  for (int i = tid; i < NT * KS * 64; i += nthreads) *(v4i*)(WP + 16 * i) = a.wp[i];
+  if (tid < 4 * NT) *(uint4*)(WB + 16 * tid) = *(const uint4*)((const unsigned char*)a.bp + 16 * tid);
+  else if (tid >= 32 && tid < 32 + 4 * NT) *(uint4*)(WB + 512 + 16 * (tid - 32)) = *(const uint4*)((const unsigned char*)a.mp + 16 * (tid - 32));
   const float rcp_pw = frcp(PW);
   if (a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
-    for (int i = tid; i < NPh * 16; i += nthreads) {   // 4 channels per lane-iteration
-      const int p = i >> 4, cd = i & 15;
+    const int ndp = CS >> 2, nd = C >> 2;              // dwords per LDS row / of real channels
+    const float rcp_ndp = frcp(ndp);
+    for (int i = tid; i < NPh * ndp; i += nthreads) {   // 4 channels per lane-iteration
+      const int p = fdiv_small(i, rcp_ndp), cd = i - p * ndp;
       const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
       const int iy = y0 + hy - 1, ix = hx - 1;
       unsigned v = a.zx4;
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+      if (cd < nd && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
         unsigned us[3] = {0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 3; j++)
@@ -105,22 +112,25 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
           v = a.chain == 1 ? addq4(pp, us[2], a.sumq) : addq4(us[2], pp, a.sumq);
         }
       }
-      *(unsigned*)(T0 + p * BD_ST + 4 * cd) = v;
+      *(unsigned*)(T0 + p * CS + 4 * cd) = v;
     }
   } else {
-    const int8_t* xb = a.x + b * (long)a.H * a.W * 64;
-    const uint4 z4 = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
-    for (int i = tid; i < NPh * 4; i += nthreads) {    // 16 bytes per lane-iteration
-      const int p = i >> 2, sg = i & 3;
+    const int8_t* xb = a.x + b * (long)a.H * a.W * C;
+    const int ngp = CS >> 3, ng = C >> 3;              // 8-byte granules per LDS row / of real channels
+    const float rcp_ngp = frcp(ngp);
+    const uint2 z2 = make_uint2(a.zx4, a.zx4);
+    for (int i = tid; i < NPh * ngp; i += nthreads) {
+      const int p = fdiv_small(i, rcp_ngp), sg = i - p * ngp;
       const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
       const int iy = y0 + hy - 1, ix = hx - 1;
-      uint4 v = z4;
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xb + (iy * a.W + ix) * 64 + 16 * sg);
-      *(uint4*)(T0 + p * BD_ST + 16 * sg) = v;
+      uint2 v = z2;
+      if (sg < ng && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint2*)(xb + (iy * a.W + ix) * C + 8 * sg);
+      *(uint2*)(T0 + p * CS + 8 * sg) = v;
     }
   }
-  // depthwise operands of this wave's channel group (requested before the barrier)
-  const int cg = wave & 3;
+  // depthwise operands of this wave's channel group (requested before the barrier): wave w owns group w % NCG and, of its
+  // pixel groups, every (NW / NCG)-th one; waves beyond NCG * (NW / NCG) sit the stage out (7 groups on 8 / 16 waves: one / two)
+  const int cg = wave % a.NCG, sub = wave / a.NCG, nsub = nwaves / a.NCG;
   v4i wdv[3];
 #pragma unroll
   for (int m = 0; m < 3; m++) wdv[m] = a.wd[(cg * 3 + m) * 64 + lane];
@@ -130,30 +140,28 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #pragma unroll
   for (int m = 0; m < 3; m++) {
     const int tap = min(4 * m + g, 8);
-    tapoff[m] = ((tap / 3) * PW + (tap % 3)) * BD_ST;
+    tapoff[m] = ((tap / 3) * PW + (tap % 3)) * CS;
   }
   const float rcp_w = frcp(a.W);
   __syncthreads();
   // ---- stage D: depthwise; unit = (output pixel group, channel group cg) ----
-  for (int pg = wave >> 2; pg < NPG; pg += nwaves / 4) {
-    const int slot = pg * 16 + r, sc = min(slot, NPo - 1);
-    const int py = fdiv_small(sc, rcp_w), px = sc - py * a.W;
-    const unsigned char* pb = T0 + (py * PW + px) * BD_ST + 16 * cg;
-    v4i acc = v4i_from(bq);
+  if (sub < nsub)
+    for (int pg = sub; pg < NPG; pg += nsub) {
+      const int slot = pg * 16 + r, sc = min(slot, NPo - 1);
+      const int py = fdiv_small(sc, rcp_w), px = sc - py * a.W;
+      const unsigned char* pb = T0 + (py * PW + px) * CS + 16 * cg;
+      v4i acc = v4i_from(bq);
 #pragma unroll
-    for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wdv[m], *(const v4i*)(pb + tapoff[m]), acc, 0, 0, 0);
-    *(unsigned*)(D + slot * BD_ST + 16 * cg + 4 * g) = rq_pack_b(acc, mu, a.rqd);
-  }
+      for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wdv[m], *(const v4i*)(pb + tapoff[m]), acc, 0, 0, 0);
+      *(unsigned*)(D + slot * CS + 16 * cg + 4 * g) = rq_pack_b(acc, mu, a.rqd);
+    }
   __syncthreads();
   // ---- stage P: projection; unit = (pixel group, 16-channel output tile) ----
   const int NU = NPG * NT;
   const float rcp_nt = frcp(NT);
-  auto project_unit = [&](int pg, int t, const v4i& wv, const int4& bb, const float4& mm) {
+  auto store_unit = [&](int pg, int t, const v4i& acc, const float4& mm) {
     const int slot = pg * 16 + r;
     const int c0 = 16 * t + 4 * g;
-    const v4i bv = *(const v4i*)(D + slot * BD_ST + 16 * g);
-    v4i acc = v4i_from(bb);
-    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, bv, acc, 0, 0, 0);
     const unsigned d = rq_pack_b(acc, mm, a.rqp);
     if (slot < NPo && c0 < a.Cout) {
       int8_t* o = a.out + ((b * a.H + y0) * (long)a.W + slot) * a.Cout + c0;   // the band's pixels are contiguous: (y0 + py) * W + px = y0 * W + slot
@@ -163,19 +171,27 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
           if (c0 + j < a.Cout) o[j] = (int8_t)(d >> (8 * j));
     }
   };
-  if (NT == 4) {
-    // 64 output channels (every layer but the heads' last): unit u = wave + 16 i is tile t = wave & 3 of pixel group
+  if (NT == 4 && KS == 1) {
+    // 64 -> 64 channels (every Lite0 layer but the heads' last): unit u = wave + 16 i is tile t = wave & 3 of pixel group
     // (wave >> 2) + 4 i, so the wave's weights / bias / multipliers are loop invariants
     const int t = wave & 3, c0 = 16 * t + 4 * g;
     const v4i wv = *(const v4i*)(WP + (t * 64 + lane) * 16);
-    const int4 bb = *(const int4*)(WP + 4096 + 4 * c0);
-    const float4 mm = *(const float4*)(WP + 4096 + 256 + 4 * c0);
-    for (int pg = wave >> 2; pg < NPG; pg += nwaves / 4) project_unit(pg, t, wv, bb, mm);
+    const int4 bb = *(const int4*)(WB + 4 * c0);
+    const float4 mm = *(const float4*)(WB + 512 + 4 * c0);
+    for (int pg = wave >> 2; pg < NPG; pg += nwaves / 4) {
+      v4i acc = v4i_from(bb);
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, *(const v4i*)(D + (pg * 16 + r) * CS + 16 * g), acc, 0, 0, 0);
+      store_unit(pg, t, acc, mm);
+    }
   } else {
     for (int u = wave; u < NU; u += nwaves) {
       const int pg = fdiv_small(u, rcp_nt), t = u - pg * NT;
       const int c0 = 16 * t + 4 * g;
-      project_unit(pg, t, *(const v4i*)(WP + (t * 64 + lane) * 16), *(const int4*)(WP + 4096 + 4 * c0), *(const float4*)(WP + 4096 + 256 + 4 * c0));
+      v4i acc = v4i_from(*(const int4*)(WB + 4 * c0));
+      const unsigned char* drow = D + (pg * 16 + r) * CS + 16 * g;
+      for (int ks = 0; ks < KS; ks++)
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*(const v4i*)(WP + ((t * KS + ks) * 64 + lane) * 16), *(const v4i*)(drow + 64 * ks), acc, 0, 0, 0);
+      store_unit(pg, t, acc, *(const float4*)(WB + 512 + 4 * c0));
     }
   }
 }

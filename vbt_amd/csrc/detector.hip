@@ -1326,10 +1326,12 @@ static bool band_ok(const vbt_model* m, int d_op, int p_op) {
   const OpRec& p = m->ops[p_op];
   const TensorRec& ti = m->tensors[d.inputs[0]];
   const TensorRec& to = m->tensors[p.output];
-  return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && ti.c == 64 && to.c <= 64 && to.h == ti.h && to.w == ti.w && ti.w <= 160;
+  return d.k == 3 && d.stride == 1 && d.pad_t == 1 && d.pad_l == 1 && ti.c % 8 == 0 && ti.c >= 16 && ti.c <= 128 && to.c <= 128 && to.h == ti.h &&
+         to.w == ti.w && ti.w <= 160;
 }
 static int band_lds(const BandArgs& a) {
-  return (a.rows + 2) * (a.W + 2) * BD_ST + (((a.rows * a.W + 15) >> 4) << 4) * BD_ST + 4096 + 512;
+  const int NT = (a.Cout + 15) / 16;
+  return (a.rows + 2) * (a.W + 2) * a.CS + (((a.rows * a.W + 15) >> 4) << 4) * a.CS + NT * a.KS * 1024 + BD_WP_TAIL;
 }
 static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc* ns, Step* out) {
   const OpRec& dop = m->ops[d_op];
@@ -1346,6 +1348,12 @@ static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc
   BandArgs& a = s.bd_args;
   memset(&a, 0, sizeof(a));
   a.H = tin.h; a.W = tin.w; a.Cout = to.c;
+  const int C = tin.c;
+  a.C = C;
+  a.CS = ((C + 15) / 16 | 1) * 16;
+  a.NCG = (C + 15) / 16;
+  a.KS = (C + 63) / 64;
+  const int NT = (to.c + 15) / 16;
   const int nb = std::max(1, (tin.h * tin.w + 319) / 320);
   a.rows = (tin.h + nb - 1) / nb;
   a.nbands = (tin.h + a.rows - 1) / a.rows;
@@ -1354,26 +1362,31 @@ static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc
   const int32_t* bqd = (const int32_t*)(m->blob.data() + dop.b_off);
   const float* mud = (const float*)(m->blob.data() + dop.m_off);
   const int8_t* wpj = (const int8_t*)(m->blob.data() + pop.w_off);
-  std::vector<v4i> pd((size_t)4 * 3 * 64, (v4i){0, 0, 0, 0}), pp((size_t)4 * 64, (v4i){0, 0, 0, 0});
+  std::vector<v4i> pd((size_t)a.NCG * 3 * 64, (v4i){0, 0, 0, 0}), pp((size_t)NT * a.KS * 64, (v4i){0, 0, 0, 0});
   int8_t* od = (int8_t*)pd.data();
-  for (int cg = 0; cg < 4; cg++)
+  for (int cg = 0; cg < a.NCG; cg++)
     for (int mi = 0; mi < 3; mi++)
       for (int lane = 0; lane < 64; lane++) {
         const int i = lane & 15, g = lane >> 4, ch = 16 * cg + i, tap = 4 * mi + g;
-        for (int j = 0; j < 16; j++) od[(((size_t)(cg * 3 + mi) * 64 + lane) * 16) + j] = (tap < 9 && j == i) ? wd[(size_t)tap * 64 + ch] : 0;
+        for (int j = 0; j < 16; j++) od[(((size_t)(cg * 3 + mi) * 64 + lane) * 16) + j] = (tap < 9 && j == i && ch < C) ? wd[(size_t)tap * C + ch] : 0;
       }
   int8_t* op_ = (int8_t*)pp.data();
-  for (int t = 0; t < 4; t++)
-    for (int lane = 0; lane < 64; lane++) {
-      const int i = lane & 15, g = lane >> 4, co = 16 * t + i;
-      for (int j = 0; j < 16; j++) op_[(((size_t)t * 64 + lane) * 16) + j] = co < to.c ? wpj[(size_t)co * 64 + 16 * g + j] : 0;
-    }
-  std::vector<int> bd(64, 0);
-  std::vector<float> md(mud, mud + 64);
-  for (int ch = 0; ch < 64; ch++) {
+  for (int t = 0; t < NT; t++)
+    for (int ks = 0; ks < a.KS; ks++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int i = lane & 15, g = lane >> 4, co = 16 * t + i;
+        for (int j = 0; j < 16; j++) {
+          const int k = 64 * ks + 16 * g + j;
+          op_[((((size_t)t * a.KS + ks) * 64 + lane) * 16) + j] = (co < to.c && k < C) ? wpj[(size_t)co * C + k] : 0;
+        }
+      }
+  std::vector<int> bd(a.NCG * 16, 0);
+  std::vector<float> md(a.NCG * 16, 0.0f);
+  for (int ch = 0; ch < C; ch++) {
     long sw = 0;
-    for (int t = 0; t < 9; t++) sw += wd[(size_t)t * 64 + ch];
+    for (int t = 0; t < 9; t++) sw += wd[(size_t)t * C + ch];
     bd[ch] = (int)((long)bqd[ch] - (long)tin.zero_point * sw);
+    md[ch] = mud[ch];
   }
   v4i *dpd, *dpp;
   int* dbd;
@@ -1898,7 +1911,7 @@ static int fuse_plan(vbt_model* m) {
         a2.hidden.push_back(op.output);
         a2.hidden.push_back(m->ops[i + 1].output);
         g.alts.push_back(a2);
-        if (band_ok(m, i + 1, i + 2) && m->tensors[op.output].c == 64) {   // the same node on row bands (band_block.h)
+        if (band_ok(m, i + 1, i + 2)) {   // the same node on row bands (band_block.h)
           Alt a3;
           Step s3;
           rc = make_band(m, i + 1, i + 2, i, &ns, &s3);
