@@ -75,3 +75,46 @@ def test_lite1_detector_parity(oracle_lib, tmp_path_factory, flags):
         for tid in range(1, it.num_tensors() - 1):
             if it.materialized(tid):
                 assert np.array_equal(it.read_tensor(tid, 2)[b], det.tensor(tid)), (flags, tid)
+
+
+def test_lite2_batch64_equals_oracle_with_the_pinned_plan(oracle_lib):
+    """BASELINE config 4 at its bench shape: 64 frames of 448x448 in one forward of the committed Lite2 container under the
+    plan bench.py pins (profiles/plan_lite2.b64.f0: row-band expand + depthwise on b11-b19, row-band BiFPN nodes / head layers
+    of width 112) - boxes, scores and counts of every frame equal the oracle's, and a second pass through the depth-3
+    pipeline with OC-SORT gives the oracle chain's rows for four of the clips."""
+    import torch
+    from oracle import ocsort_np
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    model = os.path.join(ROOT, "models", "efficientdet_lite2_synth.vbtm")
+    old = os.environ.get("VBT_PLAN_FILE")
+    os.environ["VBT_PLAN_FILE"] = os.path.join(ROOT, "profiles", "plan_lite2")
+    try:
+        n, T, S = 64, 3, 448
+        frames = np.stack([np.stack([synth.render(synth.background(300 + c, S), 5 * c + 2 * t) for c in range(n)]) for t in range(T)])
+        pipe = Pipeline(model, n, max_frames=T, fps=30.0, rows_per_frame=25)
+    finally:
+        if old is None:
+            os.environ.pop("VBT_PLAN_FILE", None)
+        else:
+            os.environ["VBT_PLAN_FILE"] = old
+    fd = torch.from_numpy(frames).cuda()
+    got = []
+    for t in range(T):
+        pipe.step(fd[t])
+        got.append(pipe.detections())
+    pipe.finish()
+    ob, os_, oc, on = oracle_lib.run_batch(model, frames.reshape(-1, S, S, 3), threads=16)
+    ob, os_, on = ob.reshape(T, n, 25, 4), os_.reshape(T, n, 25), on.reshape(T, n)
+    for t in range(T):
+        b, s, c, k = got[t]
+        assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t]), t
+    assert int(on.sum()) > 64
+    for c in (0, 17, 40, 63):
+        dets = [np.asarray([[ob[t, c, i, 1], ob[t, c, i, 0], ob[t, c, i, 3], ob[t, c, i, 2], os_[t, c, i], 0.0]
+                            for i in range(on[t, c]) if os_[t, c, i] >= 0.5], np.float64).reshape(-1, 6) for t in range(T)]
+        want = ocsort_np.track_boxes(dets, [(t + 1) / 30.0 for t in range(T)])
+        g = pipe.rows(c)
+        assert g["id"] == want["id"]
+        for k in ("time", "x", "y", "dx", "dy", "norm_plate_height", "norm_plate_width"):
+            assert np.array_equal(np.asarray(g[k]), np.asarray(want[k])), (c, k)
