@@ -72,7 +72,9 @@ __device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long 
 // NW waves per workgroup: 16 for a BiFPN node (one or two workgroups per image: the per-wave chain of units must be short), 8 for
 // the head layers (1280+ bands per launch: 16-wave workgroups fill every wave slot of a CU with two of them, so a third forward
 // in flight cannot co-reside; 8 waves on bands of <= 240 pixels interleave twice as many phases - +1.3 % end to end).
-template <int NW>
+// C64: the map has 64 channels (Lite0): row stride, channel groups and K-steps are compile-time constants (the generic
+// form costs the Lite0 pipeline 3 % end to end: 95.0 k vs 98.0 k frames/s).
+template <int NW, bool C64>
 __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, unsigned char* bd_smem) {
   constexpr int nwaves = NW, nthreads = 64 * NW;
   const long b = fdiv_small(local, frcp(a.nbands));
@@ -80,11 +82,11 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int y0 = band * a.rows, nr = min(a.rows, a.H - y0);
   const int PW = a.W + 2, NPh = (nr + 2) * PW, NPo = nr * a.W, NPG = (NPo + 15) >> 4;
-  const int C = a.C, CS = a.CS;
+  const int C = C64 ? 64 : a.C, CS = C64 ? 80 : a.CS;
   unsigned char* T0 = bd_smem;
   unsigned char* D = T0 + (a.rows + 2) * PW * CS;
   unsigned char* WP = D + (((a.rows * a.W + 15) >> 4) << 4) * CS;   // NT x KS KB of weights | 512 B bias | 512 B mult
-  const int NT = (a.Cout + 15) >> 4, KS = a.KS;
+  const int NT = (a.Cout + 15) >> 4, KS = C64 ? 1 : a.KS, NCG = C64 ? 4 : a.NCG;
   unsigned char* WB = WP + NT * KS * 1024;
 
   // ---- stage L: band + border -> T0; projection weights / bias / multipliers -> LDS ----
@@ -94,10 +96,10 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const float rcp_pw = frcp(PW);
   if (a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
-    const int ndp = CS >> 2, nd = C >> 2;              // dwords per LDS row / of real channels
+    const int ndp = C64 ? 16 : CS >> 2, nd = C >> 2;   // dwords per pixel visited (Lite0: the 64 real channels only) / of real channels
     const float rcp_ndp = frcp(ndp);
     for (int i = tid; i < NPh * ndp; i += nthreads) {   // 4 channels per lane-iteration
-      const int p = fdiv_small(i, rcp_ndp), cd = i - p * ndp;
+      const int p = C64 ? i >> 4 : fdiv_small(i, rcp_ndp), cd = i - p * ndp;
       const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
       const int iy = y0 + hy - 1, ix = hx - 1;
       unsigned v = a.zx4;
@@ -116,6 +118,17 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
     }
   } else {
     const int8_t* xb = a.x + b * (long)a.H * a.W * C;
+    if constexpr (C64) {
+      const uint4 z4 = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
+      for (int i = tid; i < NPh * 4; i += nthreads) {    // 16 bytes per lane-iteration
+        const int p = i >> 2, sg = i & 3;
+        const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
+        const int iy = y0 + hy - 1, ix = hx - 1;
+        uint4 v = z4;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xb + (iy * a.W + ix) * 64 + 16 * sg);
+        *(uint4*)(T0 + p * 80 + 16 * sg) = v;
+      }
+    } else {
     const int ngp = CS >> 3, ng = C >> 3;              // 8-byte granules per LDS row / of real channels
     const float rcp_ngp = frcp(ngp);
     const uint2 z2 = make_uint2(a.zx4, a.zx4);
@@ -127,10 +140,11 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       if (sg < ng && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint2*)(xb + (iy * a.W + ix) * C + 8 * sg);
       *(uint2*)(T0 + p * CS + 8 * sg) = v;
     }
+    }
   }
   // depthwise operands of this wave's channel group (requested before the barrier): wave w owns group w % NCG and, of its
   // pixel groups, every (NW / NCG)-th one; waves beyond NCG * (NW / NCG) sit the stage out (7 groups on 8 / 16 waves: one / two)
-  const int cg = wave % a.NCG, sub = wave / a.NCG, nsub = nwaves / a.NCG;
+  const int cg = wave % NCG, sub = wave / NCG, nsub = nwaves / NCG;
   v4i wdv[3];
 #pragma unroll
   for (int m = 0; m < 3; m++) wdv[m] = a.wd[(cg * 3 + m) * 64 + lane];
@@ -204,19 +218,32 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #define VBT_BD_HEAD_MAXPX 240
 #endif
 constexpr int BD_HEAD_WAVES = VBT_BD_HEAD_WAVES, BD_HEAD_MAXPX = VBT_BD_HEAD_MAXPX;
-#ifdef VBT_DEFINE_BAND_KERNELS   // the two entry points are not templates: exactly one translation unit (k_band.hip) defines them
-__global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+#ifdef VBT_DEFINE_BAND_KERNELS   // the entry points are not templates: exactly one translation unit (k_band.hip) defines them
+__device__ __forceinline__ int band_problem(const MultiTiles& mt) {
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < 12; i++)
     if (i < mt.n && (int)blockIdx.x >= mt.start[i]) pi = i;
-  sepconv_band_body<BD_HEAD_WAVES>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+  return pi;
+}
+__global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+  const int pi = band_problem(mt);
+  sepconv_band_body<BD_HEAD_WAVES, true>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+}
+__global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_wide_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+  const int pi = band_problem(mt);
+  sepconv_band_body<BD_HEAD_WAVES, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
 // One problem (a BiFPN node): the arguments travel in the kernel-argument segment, one dependent memory round trip
 // less at the head of a kernel that is a chain of round trips.
 __global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_kernel(BandArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
-  sepconv_band_body<BD_WAVES>(a, (int)blockIdx.x, bd_smem_dyn);
+  sepconv_band_body<BD_WAVES, true>(a, (int)blockIdx.x, bd_smem_dyn);
+}
+__global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_wide_kernel(BandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+  sepconv_band_body<BD_WAVES, false>(a, (int)blockIdx.x, bd_smem_dyn);
 }
 #endif  // VBT_DEFINE_BAND_KERNELS

@@ -2513,7 +2513,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         }
       }
       mt.start[mt.n] = acc;
-      launch_band_multi(s.d_band, mt, (unsigned)acc, s.lds_bytes, st);
+      launch_band_multi(s.d_band, mt, s.members[0].bd_args.C, (unsigned)acc, s.lds_bytes, st);
       break;
     }
     case F_EXPDW: {

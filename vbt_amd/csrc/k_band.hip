@@ -10,19 +10,23 @@ static void band_attrs() {
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_one_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_one_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
 }
 
 int launch_band_one(const BandArgs& a, unsigned grid, int lds_bytes, hipStream_t st) {
   band_attrs();
-  sepconv_band_one_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
+  if (a.C == 64) sepconv_band_one_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
+  else sepconv_band_one_wide_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
   return VBT_OK;
 }
 
-int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, unsigned grid, int lds_bytes, hipStream_t st) {
+int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, int C, unsigned grid, int lds_bytes, hipStream_t st) {
   band_attrs();
-  sepconv_band_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES, lds_bytes, st>>>(d_probs, mt);
+  if (C == 64) sepconv_band_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES, lds_bytes, st>>>(d_probs, mt);
+  else sepconv_band_wide_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES, lds_bytes, st>>>(d_probs, mt);
   return VBT_OK;
 }
 

@@ -32,7 +32,7 @@ int launch_mbconv_image(const FusedArgs& a, const ImageBundle& wb, int k, int st
                         hipStream_t st);
 // SeparableConv / BiFPN node on row bands (band_block.h): one problem by value, or several problems in one grid
 int launch_band_one(const BandArgs& a, unsigned grid, int lds_bytes, hipStream_t st);
-int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, unsigned grid, int lds_bytes, hipStream_t st);
+int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, int C, unsigned grid, int lds_bytes, hipStream_t st);   // C: channels of the maps (all problems alike)
 // whole-image expand + depthwise (expdw_block.h)
 int launch_expdw(const ExpDwArgs& a, int k, int stride, int KS64, unsigned grid, int lds_bytes, hipStream_t st);
 // network entry: stem 3x3/2 + first SeparableConv (stem_block.h)
