@@ -32,9 +32,12 @@ for rep in range(2):
 L.vbt_tracker_prof_read(out, 0)
 v = list(out)
 steps = max(v[8], 1)
-names = ["predict", "cost matrix", "assignment", "matched updates + lists", "second association", "update(None) + births", "emission + deletion"]
+names = ["predict", "cost matrix", "assignment", "unmatched lists (after the matched updates)", "second association: rest", "update(None) + births", "emission + deletion",
+         None, None, None, None, "matched Kalman updates", "second association: cost entries", "second association: assignment", "second association: recovered updates"]
 print(f"steps {steps}  mean detections {v[9] / steps:.2f}  mean live trackers {v[10] / steps:.2f}   (s_memtime ticks = 100 MHz: 10 ns)")
-tot = sum(v[:7])
+tot = sum(v[i] for i, nme in enumerate(names) if nme)
 for i, nme in enumerate(names):
-    print(f"  {nme:28s} {v[i] / steps * 10 / 1000:7.2f} us  {100 * v[i] / tot:5.1f} %")
+    if not nme:
+        continue
+    print(f"  {nme:52s} {v[i] / steps * 10 / 1000:7.2f} us  {100 * v[i] / tot:5.1f} %")
 print(f"  total                        {tot / steps * 10 / 1000:7.2f} us per stepped frame")

@@ -484,6 +484,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   }
   __syncthreads();
   if (lane < T && my_det >= 0) trk_update(st.trk[slot], sh.det[my_det], q44, q66, p.delta_t);
+  TRK_MARK(11);  // matched Kalman updates
   // unmatched lists in the reference's order (it matters: the second association sees exact ties):
   //   detections: never paired ascending, then rejected pairs in matched (= detection) order
   //   trackers  : never paired ascending, then the trackers of the rejected pairs in the same order
@@ -523,6 +524,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
     __syncthreads();
+    TRK_MARK(12);  // second association: cost entries
     if (mx > p.iou_thr) {
       int mine = -1;  // index into um_d matched to um_t[lane]
       if (nud <= nut) {
@@ -534,6 +536,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
         lap_solve(&sh.cost[0][0], MAXT, true, nut, nud, sh.r2c, sh.lap, lane);
         if (lane < nut) mine = sh.r2c[lane];
       }
+      TRK_MARK(13);  // second association: assignment
       if (lane < nut && mine >= 0 && !(sh.iou[mine][lane] < p.iou_thr)) {
         int tp = sh.um_t[lane];
         trk_update(st.trk[st.order[tp]], sh.det[sh.um_d[mine]], q44, q66, p.delta_t);
@@ -542,6 +545,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
       }
       recovered = true;
       __syncthreads();
+      TRK_MARK(14);  // second association: recovered tracks' Kalman updates (incl. the re-update over the gap)
       if (lane == 0) {  // np.setdiff1d: sorted ascending
         int n = 0;
         for (int d = 0; d < nd; d++) if ((sh.d2t[d] < 0 || sh.rej[d]) && !sh.taken[d]) sh.um_d[n++] = d;
