@@ -566,6 +566,35 @@ def other_configs(torch, dev):
                         "detector slots to the clips in proportion to the frames they have left (shard.run_schedule)"}
     guarded("corpus_1gpu", corpus)
 
+    # ---- row N2: frames at SOURCE resolution (the reference's clips are ~1080x1920 portrait): BGR -> RGB +
+    #      bilinear resize + truncating cast on the device (odt.py:10-19, track.py:171) in front of every forward ----
+    def n2_source():
+        nb, T, H, W = 64, 24, 1920, 1080
+        rng = np.random.default_rng(5)
+        src = torch.from_numpy(rng.integers(0, 256, (2, nb, H, W, 3), dtype=np.uint8))
+        dev_src = src.to(dev)
+        host_src = src.pin_memory()
+        pipe = Pipeline(MODEL, nb, max_frames=T + 4, fps=30.0)
+        res = {}
+        for name, s_ in (("resident", dev_src), ("host_fed", host_src)):
+            def body():
+                pipe.reset()
+                for t in range(T):
+                    pipe.step(s_[t % 2], stream, src_hw=(H, W), swap_rb=True)
+                pipe.close(cap=64)
+                pipe.rows_all()
+            body()                                             # first touch of the pinned pages / staging buffers
+            dt = _timed(torch, body)
+            res[name] = {"frames_per_s": nb * T / dt, "ms_per_step": dt / T * 1e3}
+        bytes_step = nb * H * W * 3
+        return {"frames_per_s": res["host_fed"]["frames_per_s"], "resident_frames_per_s": res["resident"]["frames_per_s"],
+                "ms_per_step": res["host_fed"]["ms_per_step"], "resident_ms_per_step": res["resident"]["ms_per_step"], "batch": nb,
+                "source_hw": [H, W], "h2d_bytes_per_step": bytes_step, "h2d_GBps": bytes_step / (res["host_fed"]["ms_per_step"] * 1e-3) / 1e9,
+                "roofline_frac_8d": roofline_frac_8d(res["host_fed"]["frames_per_s"], 0, nb),
+                "note": "64 uint8 1920x1080x3 BGR frames per step (398 MB): host-fed = pinned host memory -> H2D -> resize on the device -> detect + "
+                        "NMS + track (PCIe-bound: 6.2 MB per frame); resident = the same frames already in HBM"}
+    guarded("n2_1080x1920", n2_source)
+
     # ---- config 4: EfficientDet-Lite2 448x448 + OC-SORT, 64 clips per step ----
     def lite2():
         nb, T, U = 64, 120, 4
