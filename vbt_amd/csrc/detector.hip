@@ -1167,6 +1167,15 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
       v4i* d64;
       if ((rc = upload(m, w64, &d64))) return rc;
       a.wd64 = d64;
+      std::vector<long> w64c((size_t)(Cp / 16) * 64, 0);      // one byte per operand: the diagonal byte of each lane
+      int8_t* oc = (int8_t*)w64c.data();
+      for (int q = 0; q < Cp / 16; q++)
+        for (int mi = 0; mi < K64; mi++)
+          for (int lane = 0; lane < 64; lane++)
+            oc[((size_t)q * 64 + lane) * 8 + mi] = o[(((size_t)q * K64 + mi) * 64 + lane) * 16 + (lane & 15)];
+      long* d64c;
+      if ((rc = upload(m, w64c, &d64c))) return rc;
+      a.wd64c = d64c;
     }
     a.zd = tdout.zero_point; a.lod = dop.act_min; a.hid = dop.act_max;
     a.rqd = make_rq(a.zd, a.lod, a.hid);
@@ -1752,7 +1761,7 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
   const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
   const int32_t* bqd = (const int32_t*)(m->blob.data() + dop.b_off);
   const float* mud = (const float*)(m->blob.data() + dop.m_off);
-  std::vector<v4i> pe((size_t)nch * KS64 * 4 * 64, (v4i){0, 0, 0, 0}), pd((size_t)nch * 4 * KT * 64, (v4i){0, 0, 0, 0});
+  std::vector<v4i> pe((size_t)nch * KS64 * 4 * 64, (v4i){0, 0, 0, 0});
   std::vector<int> be(nch * 64, 0), bd(nch * 64, 0);
   std::vector<float> me(nch * 64, 0.0f), md(nch * 64, 0.0f);
   int8_t* o = (int8_t*)pe.data();
@@ -1766,14 +1775,14 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
             o[((((size_t)(c * KS64 + ks) * 4 + t) * 64 + lane) * 16) + j] = (ch < Ce && k < K) ? we[(size_t)ch * K + k] : 0;
           }
         }
-  int8_t* od = (int8_t*)pd.data();
+  std::vector<long> pdc((size_t)nch * 4 * 64, 0);
+  int8_t* od = (int8_t*)pdc.data();
   for (int c = 0; c < nch; c++)
     for (int cg = 0; cg < 4; cg++)
       for (int mi = 0; mi < KT; mi++)
         for (int lane = 0; lane < 64; lane++) {
           const int i = lane & 15, g = lane >> 4, ch = 64 * c + 16 * cg + i, tap = 4 * mi + g;
-          for (int j = 0; j < 16; j++)
-            od[((((size_t)(c * 4 + cg) * KT + mi) * 64 + lane) * 16) + j] = (tap < kk && j == i && ch < Ce) ? wd[(size_t)tap * Ce + ch] : 0;
+          od[(((size_t)(c * 4 + cg)) * 64 + lane) * 8 + mi] = (tap < kk && ch < Ce) ? wd[(size_t)tap * Ce + ch] : 0;
         }
   for (int ch = 0; ch < Ce; ch++) {
     long swe = 0, swd = 0;
@@ -1784,14 +1793,15 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
     bd[ch] = (int)((long)bqd[ch] - (long)te.zero_point * swd);
     md[ch] = mud[ch];
   }
-  v4i *dpe, *dpd;
+  v4i* dpe;
+  long* dpd;
   int *dbe, *dbd;
   float *dme, *dmd;
   int rc;
-  if ((rc = upload(m, pe, &dpe)) || (rc = upload(m, pd, &dpd)) || (rc = upload(m, be, &dbe)) || (rc = upload(m, bd, &dbd)) ||
+  if ((rc = upload(m, pe, &dpe)) || (rc = upload(m, pdc, &dpd)) || (rc = upload(m, be, &dbe)) || (rc = upload(m, bd, &dbd)) ||
       (rc = upload(m, me, &dme)) || (rc = upload(m, md, &dmd)))
     return rc;
-  a.we = dpe; a.wd = dpd; a.be = dbe; a.bd = dbd; a.me = dme; a.md = dmd;
+  a.we = dpe; a.wdc = dpd; a.be = dbe; a.bd = dbd; a.me = dme; a.md = dmd;
   a.rqe = make_rq(te.zero_point, eop.act_min, eop.act_max);
   a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max);
   a.zeb = (unsigned)(te.zero_point & 255) * 0x01010101u;

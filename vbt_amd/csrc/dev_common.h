@@ -67,6 +67,15 @@ __device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, 
   r1 = r1 + off;
   return pack4_u8f(r0.x, r0.y, r1.x, r1.y);
 }
+// A operand of the depthwise-as-matrix-product MFMAs (out[c][p] = sum W'[c][(t,c')] X[(t,c')][p], W' = w[t][c] delta(c,c')): the
+// 16 bytes of lane (i = lane & 15, g) hold ONE non-zero byte, byte i = the weight of the lane's tap for channel i.  Built in
+// registers from that byte (6 VALU) instead of loaded as 16 bytes per lane: the diagonal operands were ~1 KB per wave and
+// instruction out of L1, most of the weight stream of the fused MBConv kernels (L1 accesses: 18 TB/s in fused_mbconv).
+__device__ __forceinline__ v4i diag_operand(unsigned wb, int i) {
+  const unsigned sh = wb << (8 * (i & 3));
+  const int d = i >> 2;
+  return (v4i){d == 0 ? (int)sh : 0, d == 1 ? (int)sh : 0, d == 2 ? (int)sh : 0, d == 3 ? (int)sh : 0};
+}
 // exact n / d for 0 <= n < 2^20, 1 <= d <= 4096 without the ~40-instruction integer division
 __device__ __forceinline__ int fdiv_small(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
 // reciprocal for fdiv_small: one v_rcp_f32 (1 ulp) instead of the IEEE division sequence.  (n + 0.5) / d lies at least

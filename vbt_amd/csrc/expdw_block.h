@@ -45,7 +45,8 @@ struct ExpDwArgs {
   const float* me;
   Rq rqe;
   unsigned zeb;      // zero point of the expanded tensor x4
-  const v4i* wd;     // depthwise [chunk][cg][m][lane] x 16 B: row i = channel 64c + 16cg + i, k = 16g + j -> tap 4m + g, diagonal j == i
+  const long* wdc;   // depthwise [chunk][cg][lane] x 8 B: byte m = weight of tap 4m + g (0 past the kernel) for channel 64c + 16cg + (lane & 15);
+                     // the MFMA operand (that byte on the diagonal of 16) is rebuilt in registers (diag_operand)
   const int* bd;     // bias with the expanded tensor's zero point folded
   const float* md;
   Rq rqd;
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(XD_THREADS) void expdw_image_kernel(ExpDwArgs a) {
   for (int c = c_first; c < c_last; c++) {
     v4i dwv[KT];
     {
-      const v4i* w = a.wd + ((long)(c * 4 + tq) * KT) * 64 + lane;
+      const unsigned long long wc = (unsigned long long)a.wdc[(long)(c * 4 + tq) * 64 + lane];
 #pragma unroll
-      for (int m = 0; m < KT; m++) dwv[m] = w[m * 64];
+      for (int m = 0; m < KT; m++) dwv[m] = diag_operand((unsigned)(wc >> (8 * m)) & 0xffu, r);
     }
     const int4 bq = *(const int4*)(a.bd + c * 64 + 16 * tq + 4 * g);
     const float4 mu = *(const float4*)(a.md + c * 64 + 16 * tq + 4 * g);

@@ -53,6 +53,9 @@ struct FusedArgs {
   //   5x5: m < 5: (row m, column g); m = 5: (row g, column 4); m = 6: g = 0 -> (4, 4), the rest zero -> 7 instructions
   // so the B operand of (m, g) sits at a compile-time offset from one of two per-lane base addresses
   const v4i* wd64;
+  // the same operands as one byte each: [16-channel group q][lane] x 8 B, byte m = the non-zero byte of operand (q, m) of that
+  // lane; the kernels rebuild the 16-byte operand in registers (diag_operand)
+  const long* wd64c;
   // project
   const long* wp;   // packed, K = Ce_pad
   const int* bp;
@@ -384,10 +387,10 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       constexpr int KT64 = KK == 3 ? 3 : 7;
       constexpr int PGS = (16 / TXP) * S * HWX * EST;   // slot group pg -> pg + 1
       if (NT == 4 || wave < NT) {   // wave = 16-channel group of the chunk (48-channel chunks: wave 3 sits this stage out)
-        const v4i* wm = a.wd64 + ((long)(c * NT + wave) * KT64) * 64 + lane;
+        const unsigned long long wc = (unsigned long long)a.wd64c[(long)(c * NT + wave) * 64 + lane];
         v4i wreg[KT64];
 #pragma unroll
-        for (int mi = 0; mi < KT64; mi++) wreg[mi] = wm[mi * 64];
+        for (int mi = 0; mi < KT64; mi++) wreg[mi] = diag_operand((unsigned)(wc >> (8 * mi)) & 0xffu, r);
         const int4 bqm = *(const int4*)(a.bdm + c * CH + 16 * wave + 4 * g);
         const float4 mum = *(const float4*)(a.md + c * CH + 16 * wave + 4 * g);
         const int hb = TXP == 8 ? ((r >> 3) * S * HWX + (r & 7) * S) : r * S;   // window origin of slot r of group 0
