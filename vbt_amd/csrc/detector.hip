@@ -216,69 +216,88 @@ __global__ __launch_bounds__(256) void pw_b_kernel(const int8_t* __restrict__ x,
 // variant C: large K on FEW pixels (low-resolution project convs): the 4 waves of a workgroup share the same
 // 16 pixels and split K in four; partial accumulators meet in LDS, then each wave requantises one 16-channel
 // tile of every 64-channel block.  Quarter-length serial K loop, 4x the workgroups of variant B.
-template <int NBT>
+template <int NBT, int MS>
 __global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x, const v4i* __restrict__ wp, Epi e, ResArgs ra,
                                                    int8_t* __restrict__ out, long M, int K, int KS, int N, int NB) {
-  __shared__ v4i red[4][NBT * 4][64];
+  // MS pixel groups per workgroup share every weight operand a wave loads: the weights are 4/5 of the bytes this kernel pulls
+  // through L1 (4 KB of weights against 1 KB of activations per K-step and pixel group), and L1 is what it saturates
+  __shared__ v4i red[4][MS * NBT * 4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
-  const long m0 = (long)blockIdx.x * 16;
+  const long m0 = (long)blockIdx.x * (16 * MS);
   const int nb0 = blockIdx.y * NBT;
-  v4i acc[NBT][4];
+  v4i acc[MS][NBT][4];
 #pragma unroll
-  for (int i = 0; i < NBT; i++)
+  for (int s = 0; s < MS; s++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[i][t] = (v4i){0, 0, 0, 0};
-  const int8_t* p = x + min(m0 + r, M - 1) * K + 16 * g;
+    for (int i = 0; i < NBT; i++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[s][i][t] = (v4i){0, 0, 0, 0};
+  const int8_t* p[MS];
+#pragma unroll
+  for (int s = 0; s < MS; s++) p[s] = x + min(m0 + 16 * s + r, M - 1) * K + 16 * g;
   // this wave's epilogue operands (tile t = wave of every block), requested before the K loop
   int4 eb[NBT];
   float4 em[NBT];
-  unsigned eres[NBT];
+  unsigned eres[MS][NBT];
 #pragma unroll
   for (int i = 0; i < NBT; i++) {
     const int c0 = min((nb0 + i) * 64 + 16 * g + 4 * wave, NB * 64 - 4);
     eb[i] = *(const int4*)(e.bias + c0);
     em[i] = *(const float4*)(e.mult + c0);
-    eres[i] = (ra.res && (N & 3) == 0 && c0 < N) ? *(const unsigned*)(ra.res + min(m0 + r, M - 1) * N + c0) : 0u;
+#pragma unroll
+    for (int s = 0; s < MS; s++)
+      eres[s][i] = (ra.res && (N & 3) == 0 && c0 < N) ? *(const unsigned*)(ra.res + min(m0 + 16 * s + r, M - 1) * N + c0) : 0u;
   }
   const int per = (KS + 3) >> 2;
   const int k0 = wave * per, k1 = min(k0 + per, KS);
 #pragma unroll 3
   for (int ks = k0; ks < k1; ks++) {
-    v4i av = ld16(p + 64 * ks);
+    v4i av[MS];
+#pragma unroll
+    for (int s = 0; s < MS; s++) av[s] = ld16(p[s] + 64 * ks);
 #pragma unroll
     for (int i = 0; i < NBT; i++) {
       int nb = min(nb0 + i, NB - 1);
       const v4i* w = wp + ((long)(nb * KS + ks) * 4) * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[t * 64], av, acc[i][t], 0, 0, 0);
+      for (int t = 0; t < 4; t++) {
+        const v4i wv = w[t * 64];
+#pragma unroll
+        for (int s = 0; s < MS; s++) acc[s][i][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, av[s], acc[s][i][t], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < NBT; i++)
+  for (int s = 0; s < MS; s++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) red[wave][i * 4 + t][lane] = acc[i][t];
+    for (int i = 0; i < NBT; i++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) red[wave][(s * NBT + i) * 4 + t][lane] = acc[s][i][t];
   __syncthreads();
-  const long m = m0 + r;
   // wave w finishes tile t = w of every block: lane -> 4 channels (64 nb + 16 g + 4 t + j) of pixel r
 #pragma unroll
-  for (int i = 0; i < NBT; i++) {
-    const int nb = nb0 + i, t = wave;
-    const int c0 = nb * 64 + 16 * g + 4 * t;
-    if (nb < NB && c0 < N && m < M) {
-      v4i s = red[0][i * 4 + t][lane];
+  for (int s = 0; s < MS; s++) {
+    const long m = m0 + 16 * s + r;
 #pragma unroll
-      for (int w2 = 1; w2 < 4; w2++) {
-        v4i o = red[w2][i * 4 + t][lane];
-        s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+    for (int i = 0; i < NBT; i++) {
+      const int nb = nb0 + i, t = wave;
+      const int c0 = nb * 64 + 16 * g + 4 * t;
+      if (nb < NB && c0 < N && m < M) {
+        v4i sum = red[0][(s * NBT + i) * 4 + t][lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; w2++) {
+          v4i o = red[w2][(s * NBT + i) * 4 + t][lane];
+          sum[0] += o[0]; sum[1] += o[1]; sum[2] += o[2]; sum[3] += o[3];
+        }
+        unsigned d = rq_pack_i(sum, eb[i], em[i], e.rq);
+        if (ra.res && (N & 3) == 0) d = addq4(d, eres[s][i], ra.q);
+        int8_t* o = out + m * N + c0;
+        if ((N & 3) == 0) *(unsigned*)o = d;
+        else
+          for (int j = 0; j < 4; j++)
+            if (c0 + j < N) o[j] = (int8_t)(d >> (8 * j));
       }
-      unsigned d = rq_pack_i(s, eb[i], em[i], e.rq);
-      if (ra.res && (N & 3) == 0) d = addq4(d, eres[i], ra.q);
-      int8_t* o = out + m * N + c0;
-      if ((N & 3) == 0) *(unsigned*)o = d;
-      else
-        for (int j = 0; j < 4; j++)
-          if (c0 + j < N) o[j] = (int8_t)(d >> (8 * j));
     }
   }
 }
@@ -2336,10 +2355,14 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         // one 64-channel block per workgroup (16 KB of LDS for the cross-wave reduction, twice the workgroups) rather than two
         // (32 KB): +1.4 % end to end with three forwards in flight - the workgroups of one launch then fit the CUs in one round
         static const int nbt_max = getenv("VBT_PWC_NBT") ? atoi(getenv("VBT_PWC_NBT")) : 1;
+        static const int ms_env = getenv("VBT_PWC_MS") ? atoi(getenv("VBT_PWC_MS")) : 2;
         int nbt = std::min(s.NB, nbt_max);
-        dim3 grid((unsigned)((M + 15) / 16), (unsigned)((s.NB + nbt - 1) / nbt));
-        if (nbt == 1) pw_c_kernel<1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
-        else pw_c_kernel<2><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+        // two pixel groups per workgroup (half the weight bytes through L1) as long as the grid still has two workgroups per CU
+        const int ms = (ms_env >= 2 && nbt == 1 && ((M + 31) / 32) * s.NB >= 512) ? 2 : 1;
+        dim3 grid((unsigned)((M + 16 * ms - 1) / (16 * ms)), (unsigned)((s.NB + nbt - 1) / nbt));
+        if (ms == 2) pw_c_kernel<1, 2><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+        else if (nbt == 1) pw_c_kernel<1, 1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+        else pw_c_kernel<2, 1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
       } else {
         long waves = (M + 15) / 16;
         unsigned gx = (unsigned)((waves + 3) / 4);
