@@ -257,6 +257,19 @@ struct LapShared {
 
 __device__ void lap_solve(const double* C, int ld, bool tr, int nr, int nc, int* row2col, LapShared& S, int lane) {
   const double INF = __builtin_inf();
+  if (nr == 1) {
+    // One row (OC-SORT's second association usually has one unmatched detection): the first augmenting path of the solver
+    // ends at the cheapest column; among equal costs it takes the LAST one it scans, and it scans remaining[] = nc-1 ... 0,
+    // i.e. the lowest column index.  No dual update can change a one-row result.
+    double c = lane < nc ? (tr ? C[lane * ld] : C[lane]) : INF;
+    double lowest = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lowest = fmin(lowest, __shfl_xor(lowest, o));
+    const unsigned long long cand = __ballot(lane < nc && c == lowest);
+    if (lane == 0) row2col[0] = __ffsll((long long)cand) - 1;
+    __syncthreads();
+    return;
+  }
   double v = 0.0;
   if (lane < nr) { S.u[lane] = 0.0; S.col4row[lane] = -1; }
   if (lane < nc) { S.row4col[lane] = -1; S.path[lane] = -1; }
