@@ -1,4 +1,5 @@
-// EfficientDet-Lite int8 detector on gfx950 (MI355X): kernels + execution plan + C ABI.
+// EfficientDet-Lite int8 detector on gfx950 (MI355X): single-op kernels, execution plan (planner + autotuner) and the C ABI.
+// The fused kernel families live in their own translation units (k_*.hip, reached through launchers.h).
 //
 // Replaces the TFLite interpreter invoke at reference odt.py:58-66 (signature_fn(images=...)).
 // Arithmetic contract = the kernels tflite-runtime 2.14 executes on x86-64 (XNNPACK delegate by default, TFLite builtin
@@ -8,11 +9,12 @@
 //   post:  LOGISTIC / DEQUANTIZE tables, centre-size decode in double rounded to float once per quantity, greedy NMS in
 //          (score desc, anchor asc) order                                                            (detection_postprocess.cc)
 // Design (MI355X-first):
-//   * activations int8 NHWC, batch-major [B][H][W][C]; pointwise convs run on the int8 MFMA
-//     (v_mfma_i32_16x16x32_i8) with the WEIGHTS as the A operand so every lane ends up holding 16
-//     consecutive output channels of one pixel -> one 16-byte coalesced store per lane;
-//   * depthwise convs convert bytes with v_cvt_f32_ubyteN and accumulate with v_fma_f32 (exact:
-//     |sum| < 2^24), 4 channels per lane so a wave reads contiguous NHWC channel vectors;
+//   * activations int8 NHWC, batch-major [B][H][W][C]; pointwise convs run on the double-rate int8 MFMA
+//     (v_mfma_i32_16x16x64_i8; the stem conv and the fused tiles' expand / project stages on v_mfma_i32_16x16x32_i8) with the
+//     WEIGHTS as the A operand so every lane ends up holding 16 consecutive output channels of one pixel -> one 16-byte
+//     coalesced store per lane;
+//   * stand-alone depthwise convs: row / column walkers (v_cvt_f32_ubyteN + v_fma_f32, exact: |sum| < 2^24, 4 channels per
+//     lane on contiguous NHWC channel vectors) or LDS tiles on the matrix pipe (diagonal-embedded weights);
 //   * zero points are folded into the bias on the host at load time; padding uses the zero point;
 //   * decode + NMS: one workgroup per frame, 256-bin score histogram -> bitonic sort of the top
 //     candidates in LDS -> greedy suppression by one wavefront with ballot/shuffle.
