@@ -892,6 +892,9 @@ struct Step {
   int band_tiles = 0;           // workgroups per image of this problem
   // F_EXPDW: expand + depthwise on whole images, expanded channels split over workgroups (expdw_block.h; op = depthwise op)
   ExpDwArgs xd;
+  ExpDw2Args xd2;              // the same step on the second form of the kernel (expdw2_block.h); variant 100 + cpw runs it
+  bool xd2_ok = false;
+  int xd2_lds = 0, xd2_gpw = 0;
   // F_MBCONV on a low-resolution map: per-chunk weight records of the whole-image kernel (data == nullptr: not built)
   ImageBundle ib = {nullptr, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -1749,6 +1752,8 @@ static bool expdw_ok(const vbt_model* m, int e_op, int d_op) {
   const ExpDwGeom g = expdw_choose(tin.h, tin.w, tout.h, tout.w, d.k, d.stride, d.pad_t, d.pad_l, ((tin.c + 15) / 16 | 1) * 16);
   return g.t0_bytes + g.e_bytes + g.d_bytes <= 160 * 1024;
 }
+static int make_expdw2(vbt_model* m, int e_op, int d_op, Step* s, const std::vector<v4i>& pe, const std::vector<int>& be, const std::vector<float>& me,
+                       const std::vector<int>& bd, const std::vector<float>& md);
 static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
   const OpRec& eop = m->ops[e_op];
   const OpRec& dop = m->ops[d_op];
@@ -1832,7 +1837,128 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
     s.weight_bytes += m->op_steps[oi].weight_bytes;
     s.macs_per_frame += m->op_steps[oi].macs_per_frame;
   }
+  if ((rc = make_expdw2(m, e_op, d_op, &s, pe, be, me, bd, md))) return rc;
   *out = s;
+  return VBT_OK;
+}
+
+// ---- second form of the expand + depthwise kernel (expdw2_block.h): stride 1, Cin % 16 == 0 ----
+// LDS cycles of the depthwise operand reads (ds_read_b128: four groups of 16 lanes, one cycle per group when its 16-byte pieces
+// fall on distinct quarters of the 64 banks; equal addresses broadcast) summed over the positions of a band, for a row stride EYS
+static long xd2_read_cycles(int OHb, int XB, int EYS) {
+  static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                 {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                 {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                 {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  const int NPOS = OHb * XB;
+  long cycles = 0;
+  for (int pg = 0; pg * 16 < NPOS; pg++)
+    for (int k = 0; k < 4; k++) {
+      std::vector<int> seen[16];
+      int worst = 1;
+      for (int j = 0; j < 16; j++) {
+        const int lane = grp[k][j], r = lane & 15, g = lane >> 4, n = std::min(pg * 16 + r, NPOS - 1);
+        const int addr = (n / XB) * EYS + (n % XB) * 16 + (g >> 1) * EYS + 16 * (g & 1);
+        std::vector<int>& v = seen[(addr >> 4) & 15];
+        if (std::find(v.begin(), v.end(), addr) == v.end()) v.push_back(addr);
+        worst = std::max(worst, (int)v.size());
+      }
+      cycles += worst;
+    }
+  return cycles;
+}
+struct ExpDw2Geom { bool ok; int nbands, brows, XB, EQS, EYS, e_bytes, PS, pe_off, pd_off, lds, gpw; };
+static ExpDw2Geom expdw2_geom(int H, int W, int OH, int OW, int k, int pad_t, int KS64, int nbands) {
+  ExpDw2Geom g{};
+  g.brows = (OH + nbands - 1) / nbands;
+  g.nbands = (OH + g.brows - 1) / g.brows;
+  g.XB = (OW + 3) / 4;
+  const int KT2 = (k + 1) / 2, PW = OW - 1 + k;
+  g.EQS = (4 * PW + 15) & ~15;
+  int in_rows = 0;
+  for (int b = 0; b < g.nbands; b++) {
+    const int oy0 = b * g.brows, oy1 = std::min(oy0 + g.brows, OH);
+    const int lo = std::max(oy0 - pad_t, 0), hi = std::min(oy0 - pad_t + (oy1 - oy0) - 1 + k, H);
+    in_rows = std::max(in_rows, hi - lo);
+  }
+  long best = -1;
+  for (int pad = 0; pad < 256; pad += 16) {
+    const long cyc = xd2_read_cycles(g.brows, g.XB, 16 * g.EQS + pad);
+    if (best < 0 || cyc < best) { best = cyc; g.EYS = 16 * g.EQS + pad; }
+  }
+  const int PHe = g.brows - 1 + 2 * KT2;   // the last MFMA of a 5x5 (3x3) reads one row past the kernel: zero weights, but the row must exist
+  g.e_bytes = (PHe * g.EYS + 32 + 15) & ~15;
+  int ps4 = g.brows * OW;
+  while ((ps4 & 31) != 2) ps4++;
+  g.PS = 4 * ps4;
+  g.pe_off = g.e_bytes + 16 * g.PS;
+  g.pd_off = g.pe_off + 16 * (KS64 * 256 + 32);
+  g.lds = g.pd_off + 16 * (KT2 * 256 + 32);
+  const int npgi = (in_rows * W + 15) / 16, need = (npgi + 3) / 4;
+  g.gpw = need <= 2 ? 2 : need <= 4 ? 4 : need <= 7 ? 7 : 0;
+  g.ok = g.gpw > 0 && g.lds <= 100 * 1024 && g.brows * g.XB <= 16 * XD2_NPG;
+  return g;
+}
+static ExpDw2Geom expdw2_choose(int H, int W, int OH, int OW, int k, int pad_t, int KS64) {
+  ExpDw2Geom g{};
+  for (int nb = 1; nb <= OH; nb++) {
+    g = expdw2_geom(H, W, OH, OW, k, pad_t, KS64, nb);
+    if (g.ok) return g;
+  }
+  g.ok = false;
+  return g;
+}
+// fills s->xd2 from the finished first-form arguments s->xd and the host images of its expand weights / biases / multipliers
+static int make_expdw2(vbt_model* m, int e_op, int d_op, Step* s, const std::vector<v4i>& pe, const std::vector<int>& be, const std::vector<float>& me,
+                       const std::vector<int>& bd, const std::vector<float>& md) {
+  static const bool enabled = !(getenv("VBT_XD_V2") && atoi(getenv("VBT_XD_V2")) == 0);
+  const OpRec& dop = m->ops[d_op];
+  const ExpDwArgs& a1 = s->xd;
+  s->xd2_ok = false;
+  const int KS64 = (a1.Cin + 63) / 64;
+  if (!enabled || dop.stride != 1 || (dop.k != 3 && dop.k != 5) || a1.Cin % 16 != 0 || KS64 < 2 || KS64 > 4) return VBT_OK;
+  const ExpDw2Geom geo = expdw2_choose(a1.H, a1.W, a1.OH, a1.OW, dop.k, a1.pad_t, KS64);
+  if (!geo.ok) return VBT_OK;
+  ExpDw2Args& a = s->xd2;
+  memset(&a, 0, sizeof(a));
+  a.H = a1.H; a.W = a1.W; a.Cin = a1.Cin; a.OH = a1.OH; a.OW = a1.OW; a.Ce = a1.Ce;
+  a.pad_t = a1.pad_t; a.pad_l = a1.pad_l;
+  a.nchunks = a1.nchunks; a.cpw = 1; a.nbands = geo.nbands; a.brows = geo.brows;
+  a.XB = geo.XB; a.EQS = geo.EQS; a.EYS = geo.EYS; a.e_bytes = geo.e_bytes; a.PS = geo.PS; a.pe_off = geo.pe_off; a.pd_off = geo.pd_off;
+  a.rqe = a1.rqe; a.zeb = a1.zeb; a.rqd = a1.rqd;
+  const TensorRec& te = m->tensors[m->ops[e_op].output];
+  const int Ce = te.c, nch = a.nchunks, kk = dop.k, KT2 = (kk + 1) / 2;
+  const int NE = KS64 * 256 + 32, ND = KT2 * 256 + 32;
+  const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
+  std::vector<v4i> ppe((size_t)nch * NE), ppd((size_t)nch * ND);
+  for (int c = 0; c < nch; c++) {
+    v4i* e = &ppe[(size_t)c * NE];
+    memcpy(e, &pe[(size_t)c * KS64 * 256], sizeof(v4i) * KS64 * 256);
+    memcpy(e + KS64 * 256, &be[c * 64], 256);
+    memcpy(e + KS64 * 256 + 16, &me[c * 64], 256);
+    v4i* d = &ppd[(size_t)c * ND];
+    unsigned* tab = (unsigned*)d;
+    for (int q = 0; q < 16; q++)
+      for (int mi = 0; mi < KT2; mi++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int i = lane & 15, g = lane >> 4, dx = i >> 2, cc = i & 3, ch = 64 * c + 4 * q + cc, ty = 2 * mi + (g >> 1);
+          unsigned w4 = 0;
+          for (int j = 0; j < 4; j++) {
+            const int tx = 4 * (g & 1) + j - dx;
+            if (ty < kk && tx >= 0 && tx < kk && ch < Ce) w4 |= (unsigned)(uint8_t)wd[(size_t)(ty * kk + tx) * Ce + ch] << (8 * j);
+          }
+          tab[(q * KT2 + mi) * 64 + lane] = w4;
+        }
+    memcpy(d + KT2 * 256, &bd[c * 64], 256);
+    memcpy(d + KT2 * 256 + 16, &md[c * 64], 256);
+  }
+  v4i *dpe, *dpd;
+  int rc;
+  if ((rc = upload(m, ppe, &dpe)) || (rc = upload(m, ppd, &dpd))) return rc;
+  a.pe = dpe; a.pd = dpd;
+  s->xd2_ok = true;
+  s->xd2_lds = geo.lds;
+  s->xd2_gpw = geo.gpw;
   return VBT_OK;
 }
 
@@ -2552,9 +2678,22 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       break;
     }
     case F_EXPDW: {
-      ExpDwArgs a = s.xd;
       const OpRec& eop = m->ops[s.e_op];
       const OpRec& dop = m->ops[s.d_op];
+      // variant: chunks per workgroup on the first form of the kernel, 100 + chunks per workgroup on the second; -1: heuristic default
+      if (s.xd2_ok && (s.variant >= 100 || s.variant < 0)) {
+        ExpDw2Args a = s.xd2;
+        a.x = TP(eop.inputs[0]);
+        a.out = out;
+        a.cpw = s.variant >= 100 ? s.variant - 100 : std::max(1, (a.nchunks * a.nbands * B + 1023) / 1024);   // default: about four workgroups per CU
+        a.cpw = std::min(a.cpw, a.nchunks);
+        const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
+        const int rc = launch_expdw2(a, dop.k, (a.Cin + 63) / 64, s.xd2_gpw, (unsigned)(B * ngroups * a.nbands), s.xd2_lds, st);
+        if (rc) return rc;
+        break;
+      }
+      if (s.variant >= 100) { set_error("expand + depthwise: plan asks for the second kernel form on a step that does not support it"); return VBT_ERR_ARG; }
+      ExpDwArgs a = s.xd;
       a.x = TP(eop.inputs[0]);
       a.out = out;
       a.cpw = s.variant > 0 ? s.variant : std::max(1, (a.nchunks * a.nbands * B + 511) / 512);   // default: about two workgroups per CU
@@ -2675,6 +2814,9 @@ static void autotune(vbt_model* m) {
           cand.clear();
           for (int cpw : {1, 2, 3, 4, 6})
             if (cpw <= st.xd.nchunks) cand.push_back(cpw);
+          if (st.xd2_ok)
+            for (int cpw : {1, 2, 3, 4, 6})
+              if (cpw <= st.xd.nchunks) cand.push_back(100 + cpw);
         }
         double best = 1e30;
         int bestv = -1;

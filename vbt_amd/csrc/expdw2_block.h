@@ -1,0 +1,320 @@
+// Low-resolution MBConv, first half (expand 1x1 + ReLU6 -> depthwise kxk, stride 1), second form of expdw_block.h.  Same split
+// of the work - workgroup (image b, row band, channel group) produces `cpw` 64-channel chunks of the depthwise output, the
+// projection runs afterwards as a pointwise GEMM - and the same arithmetic (int32 accumulation, one float requantisation per
+// element), but organised around what the stage stamps of tools/probes/xd_probe.hip showed for the first form: its stages did not
+// overlap at all (LDS operand reads 40 %, MFMA 20 %, requantisation 15 %, and a third of a chunk's time in per-unit address
+// arithmetic, exposed parameter loads and three barriers), and the depthwise read every expanded element k*k times from LDS.
+//
+//   * The block input never goes through LDS.  A wave owns fixed pixel groups; their expand B operands (16 pixels x 64 input
+//     channels per MFMA) are loaded from global memory into registers once and serve every chunk.  No T0 tile (45 KB at
+//     20x20x112), no LDS reads and no address arithmetic in the expand stage.
+//   * Depthwise as a band-Toeplitz matrix product instead of a diagonal one.  The expanded chunk lives in LDS QUAD-PLANAR:
+//     E[row][channel quad][x][4 channels].  One MFMA multiplies A[(dx, c)][(ty, x', c')] = w[ty][x' - dx][c] delta(c, c')
+//     (4 output columns dx x 4 channels c; K = 2 kernel rows x 8 input columns x 4 channels) with B = 16 positions (output row,
+//     block of 4 output columns), one aligned 16-byte LDS read per lane: 10 taps per output and instruction instead of 4, i.e.
+//     2 MFMAs + 2 reads per 256 outputs for 3x3 (was 3) and 3 for 5x5 (was 7).  A lane ends with the 4 channels of one output
+//     pixel: one dword store.
+//   * The depthwise output chunk is staged quad-planar too (D[quad][pixel][4]): conflict-free dword stores, and the copy to
+//     the tensor gathers a pixel's 16 channels with four dword reads.
+//   * Two barriers per chunk instead of three: the copy-out of chunk c runs in the same interval as the expand of chunk c + 1.
+//   * A chunk's parameters (expand weights, depthwise weights, biases, multipliers: 21-25 KB) are fetched ONCE per workgroup, three
+//     16-byte loads per thread issued a stage ahead, and handed to the waves through LDS.  Per-wave loads of the same data cost 22
+//     vector-memory instructions per wave and chunk - 8 waves x 22 x 16 address cycles = 2800 cycles of the CU's one address path,
+//     the fixed cost the stage stamps showed in every interval.
+//   * LDS: E 39 KB + D 26 KB at 20x20 (was 120 KB): two workgroups per CU, so one's expand overlaps the other's depthwise.
+// Stride-2 blocks and inputs whose channel count is not a multiple of 16 stay on expdw_block.h.
+#pragma once
+#include <type_traits>
+
+#ifndef XD2_KO_D
+#define XD2_KO_D 0   // probe builds: knock-outs of the depthwise stage (1 no store, 2 no requantisation, 3 no MFMA, 4 no LDS read, 5 no address arithmetic)
+#endif
+#ifndef XD2_KO_E
+#define XD2_KO_E 0   // the same for the expand stage (1 no store, 2 no requantisation, 3 no MFMA)
+#endif
+#ifdef VBT_XD_PROF
+#define XD2_STAMP(k) do { if (tid == 0) a.prof[(long)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XD2_STAMP(k) do { } while (0)
+#endif
+
+constexpr int XD2_WAVES = 8, XD2_THREADS = 64 * XD2_WAVES;
+
+struct ExpDw2Args {
+  const int8_t* x;   // [B][H][W][Cin]
+  int8_t* out;       // [B][OH][OW][Ce]: the graph's depthwise output tensor
+  int H, W, Cin, OH, OW, Ce;
+  int pad_t, pad_l;
+  int nchunks, cpw;  // 64-channel chunks in all / per workgroup
+  int nbands, brows; // row bands per image / output rows per band
+  int XB;            // blocks of 4 output columns per row
+  int EQS, EYS;      // E: bytes per (row, quad) = 4 * padded width rounded to 16; bytes per row = 16 * EQS + bank-spreading pad
+  int e_bytes;       // LDS bytes of E (tallest band, + slack for the reads past the last row)
+  int PS;            // D: bytes per quad plane (4 * pixels of the tallest band, rounded so that PS / 4 = 2 mod 32)
+  int pe_off;        // LDS byte offsets of the parameter areas Pe / Pd (behind D)
+  int pd_off;
+  // per chunk, 16-byte pieces, copied to LDS as they are:
+  const v4i* pe;     // expand: weights [ks][t][lane] x 16 B (row i of tile t = channel 64 c + 16 t + i, k = 64 ks + 16 g + j) | bias (input zero
+                     // point folded) x 64 | multipliers x 64                                          = KS64 * 256 + 32 pieces
+  const v4i* pd;     // depthwise: [quad][mi][lane] dwords, byte j = w[2 mi + (g >> 1)][4 (g & 1) + j - dx][64 c + 4 quad + cc] for A row
+                     // (lane & 15) = 4 dx + cc (0 outside the kernel; the MFMA operand - dword j = that byte at byte position cc - is rebuilt
+                     // in registers) | bias (expanded zero point folded) x 64 | multipliers x 64       = KT2 * 256 + 32 pieces
+  Rq rqe;
+  unsigned zeb;      // zero point of the expanded tensor x4
+  Rq rqd;
+#ifdef VBT_XD_PROF
+  unsigned long long* prof;
+#endif
+};
+
+// A operand of the band-Toeplitz depthwise MFMA from its four bytes: dword j holds byte j at byte position c = row & 3
+__device__ __forceinline__ v4i toeplitz_operand(unsigned w4, int c) {
+  const int sh = 8 * c;
+  return (v4i){(int)((w4 & 0xffu) << sh), (int)(((w4 >> 8) & 0xffu) << sh), (int)(((w4 >> 16) & 0xffu) << sh), (int)((w4 >> 24) << sh)};
+}
+
+constexpr int XD2_NPG = 8;   // position groups a band may have (128 positions = 512 output pixels)
+template <int PG, class F, class FC>
+__device__ __forceinline__ void d_pair(F& d_units, FC full_c, int NPGo) {
+  if constexpr (PG < XD2_NPG) {
+    if (PG + 1 < NPGo) d_units(full_c, std::integral_constant<int, 2>{}, std::integral_constant<int, PG>{});
+    else if (PG < NPGo) d_units(full_c, std::integral_constant<int, 1>{}, std::integral_constant<int, PG>{});
+    if (PG + 2 < NPGo) d_pair<PG + 2>(d_units, full_c, NPGo);
+  }
+}
+
+// KK: depthwise kernel size (stride 1); KS64: 64-channel K steps of the expand; GPW: input pixel groups a wave owns (>= ceil(pixel groups / 4))
+template <int KK, int KS64, int GPW>
+__global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char xd2_smem[];
+  constexpr int KT2 = (KK + 1) / 2;   // depthwise MFMAs per unit: two kernel rows each
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  XD2_STAMP(0);
+  const int ngroups = fdiv_small(a.nchunks + a.cpw - 1, frcp(a.cpw));
+  const int per_image = ngroups * a.nbands;
+  const long b = fdiv_small((int)blockIdx.x, frcp(per_image));
+  const int rem = blockIdx.x - (int)b * per_image;
+  const int band = fdiv_small(rem, frcp(ngroups));
+  const int grp = rem - band * ngroups;
+  const int oy0 = band * a.brows, oy1 = min(oy0 + a.brows, a.OH), OHb = oy1 - oy0;
+  const int iy_lo = max(oy0 - a.pad_t, 0), iy_hi = min(oy0 - a.pad_t + OHb - 1 + KK, a.H);
+  const int erow0 = iy_lo + a.pad_t - oy0;                       // E row of input row iy_lo
+  const int HW = (iy_hi - iy_lo) * a.W, OHW = OHb * a.OW;        // pixels of the band: input / output
+  const int NPOS = OHb * a.XB, NPGo = (NPOS + 15) >> 4;          // depthwise positions (row, 4-column block) and their groups of 16
+  unsigned char* E = xd2_smem;
+  unsigned char* D = E + a.e_bytes;
+  const int c_first = grp * a.cpw, c_last = min(c_first + a.cpw, a.nchunks);
+
+  // ---- expand stage, per-lane constants: wave = (tile pair tp, pixel group phase wq); lane (r, g) = pixel r of a group, K slice g ----
+  const int tp = wave >> 2, wq = wave & 3;
+  v4i xin[GPW][KS64];
+  int eoff[GPW];   // E byte offset of this lane's dword for tile 2 tp (channel quad 8 tp + g), -1: no such pixel
+  {
+    const int8_t* xb = a.x + (b * (long)a.H + iy_lo) * a.W * a.Cin;
+    const float rcp_w = frcp(a.W);
+#pragma unroll
+    for (int i = 0; i < GPW; i++) {
+      const int p = (wq + 4 * i) * 16 + r, pc = min(p, HW - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS64; ks++) {
+        const int k0 = 64 * ks + 16 * g;   // Cin % 16 == 0: a K slice lies inside the pixel's channels or wholly in the zero-weight padding
+        xin[i][ks] = k0 < a.Cin ? *(const v4i*)(xb + (long)pc * a.Cin + k0) : (v4i){0, 0, 0, 0};
+      }
+      const int py = fdiv_small(pc, rcp_w), px = pc - py * a.W;
+      eoff[i] = p < HW ? (py + erow0) * a.EYS + (px + a.pad_l) * 4 + (8 * tp + g) * a.EQS : -1;
+    }
+  }
+  // ---- parameters of a chunk: global -> registers (a stage ahead) -> LDS -> the waves that need them ----
+  constexpr int NE = KS64 * 256 + 32, ND = KT2 * 256 + 32;                     // 16-byte pieces per chunk
+  constexpr int NPE = (NE + XD2_THREADS - 1) / XD2_THREADS, NPD = (ND + XD2_THREADS - 1) / XD2_THREADS;
+  unsigned char* Pe = xd2_smem + a.pe_off;
+  unsigned char* Pd = xd2_smem + a.pd_off;
+  v4i pe_r[NPE], pd_r[NPD];
+  // No load is issued under a condition (indices are clamped instead) and none stays in flight across the copy-out's stores: gfx9
+  // counts loads and stores in one vmcnt, and a conditional prefetch or a store loop between a load and its use makes the compiler's
+  // waits conservative - the stage then waits for loads it has only just issued.
+  auto fetch_params = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < NPD; k++) pd_r[k] = a.pd[(long)c * ND + min(tid + k * XD2_THREADS, ND - 1)];
+#pragma unroll
+    for (int k = 0; k < NPE; k++) pe_r[k] = a.pe[(long)c * NE + min(tid + k * XD2_THREADS, NE - 1)];
+  };
+  auto put_pe = [&]() {
+#pragma unroll
+    for (int k = 0; k < NPE; k++) *(v4i*)(Pe + 16 * min(tid + k * XD2_THREADS, NE - 1)) = pe_r[k];
+  };
+  auto put_pd = [&]() {
+#pragma unroll
+    for (int k = 0; k < NPD; k++) *(v4i*)(Pd + 16 * min(tid + k * XD2_THREADS, ND - 1)) = pd_r[k];
+  };
+  fetch_params(c_first);
+  asm volatile("" ::: "memory");   // the compiler otherwise sinks loads to their first use and waits for them there
+  const int cq0 = 2 * wave;        // depthwise stage: this wave's channel quads are cq0, cq0 + 1
+  // E <- zero point: border, rows outside the image and the padding columns keep it (the expand writes real pixels only)
+  {
+    const uint4 z4 = make_uint4(a.zeb, a.zeb, a.zeb, a.zeb);
+    for (int i = tid; i < (a.e_bytes >> 4); i += XD2_THREADS) *(uint4*)(E + 16 * i) = z4;
+  }
+  // ---- depthwise stage, per-lane constants: wave owns channel quads 2 wave, 2 wave + 1; lane (r, g) = position r of a group, K slice g ----
+  // E byte offset of this lane's operand (kernel rows 0 / 1, column half g & 1, quad cq0) and D byte offset of its output dword for
+  // every position group, once per kernel: the stage itself then has no address arithmetic (it was a quarter of its vector instructions)
+  int dbase[XD2_NPG], ddoff[XD2_NPG];   // ddoff -1: no such output pixel
+  {
+    const int gofs = (g >> 1) * a.EYS + 16 * (g & 1) + cq0 * a.EQS;
+    const float rcp_xb = frcp(a.XB);
+#pragma unroll
+    for (int pg = 0; pg < XD2_NPG; pg++) {
+      const int n = pg * 16 + r, nc = min(n, NPOS - 1);
+      const int y = fdiv_small(nc, rcp_xb), xk = nc - y * a.XB;
+      dbase[pg] = y * a.EYS + xk * 16 + gofs;
+      const int ox = 4 * xk + g;
+      ddoff[pg] = (n < NPOS && ox < a.OW) ? (y * a.OW + ox) * 4 + cq0 * a.PS : -1;
+    }
+  }
+  // ---- copy-out: D (quad-planar) -> the depthwise output tensor, 16 bytes per lane ----
+  auto copy_out = [&](int c) {
+    const int nv = min(64, a.Ce - 64 * c) >> 4;   // 16-byte parts of this chunk (Ce % 16 == 0)
+    const float rcp_nv = frcp(nv);
+    int8_t* ob = a.out + (b * (long)a.OH + oy0) * a.OW * a.Ce + 64 * c;
+    for (int i = tid; i < OHW * nv; i += XD2_THREADS) {
+      const int slot = fdiv_small(i, rcp_nv), part = i - slot * nv;
+      const unsigned char* s = D + 4 * part * a.PS + 4 * slot;
+      *(uint4*)(ob + (long)slot * a.Ce + 16 * part) =
+          make_uint4(*(const unsigned*)s, *(const unsigned*)(s + a.PS), *(const unsigned*)(s + 2 * a.PS), *(const unsigned*)(s + 3 * a.PS));
+    }
+  };
+  put_pe();
+  __syncthreads();
+  XD2_STAMP(1);
+  for (int c = c_first; c < c_last; c++) {
+    // Interval A: depthwise parameters of chunk c -> LDS (every wave took chunk c - 1's out of Pd at the start of its depthwise stage,
+    // before the barrier behind us); the next chunk's parameters requested; the previous chunk's output leaves; expand of chunk c.
+    put_pd();
+    fetch_params(min(c + 1, c_last - 1));   // two intervals ahead of put_pe: a depthwise stage can be shorter than a round trip to memory
+    asm volatile("" ::: "memory");
+    if (c > c_first) copy_out(c - 1);
+    v4i ew[2][KS64];
+    int4 eb[2];
+    float4 em[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+#pragma unroll
+      for (int ks = 0; ks < KS64; ks++) ew[tt][ks] = *(const v4i*)(Pe + 16 * ((ks * 4 + 2 * tp + tt) * 64 + lane));
+      eb[tt] = *(const int4*)(Pe + 16 * (KS64 * 256) + 4 * (16 * (2 * tp + tt) + 4 * g));
+      em[tt] = *(const float4*)(Pe + 16 * (KS64 * 256 + 16) + 4 * (16 * (2 * tp + tt) + 4 * g));
+    }
+    // ---- stage E: expand chunk c; unit = (pixel group i, tile tt of the pair); every B operand is in registers ----
+    {
+      auto e_stage = [&](auto full_c) {
+        constexpr int FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          v4i acc[GPW];
+#pragma unroll
+          for (int i = 0; i < GPW; i++) acc[i] = v4i_from(eb[tt]);
+#pragma unroll
+          for (int ks = 0; ks < KS64; ks++)
+#pragma unroll
+            for (int i = 0; i < GPW; i++) {
+#if XD2_KO_E >= 3
+              { const v4i xv = xin[i][ks], wv = ew[tt][ks]; asm volatile("" ::"v"(xv), "v"(wv)); }
+#else
+              acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ew[tt][ks], xin[i][ks], acc[i], 0, 0, 0);
+#endif
+            }
+#pragma unroll
+          for (int i = 0; i < GPW; i++) {
+            const int eo = eoff[i];
+#if XD2_KO_E >= 2
+            asm volatile("" ::"v"(acc[i]), "v"(eo));
+#else
+            const unsigned val = rq_pack_b<FULL>(acc[i], em[tt], a.rqe);
+#if XD2_KO_E >= 1
+            asm volatile("" ::"v"(val), "v"(eo));
+#else
+            if (eo >= 0) *(unsigned*)(E + eo + tt * 4 * a.EQS) = val;
+#endif
+#endif
+          }
+        }
+      };
+      if (a.rqe.full) e_stage(std::integral_constant<int, 1>{}); else e_stage(std::integral_constant<int, 0>{});
+    }
+    __syncthreads();   // E complete, D free
+    XD2_STAMP(2 + 2 * (c - c_first));
+    // ---- stage D: depthwise on chunk c; unit = (position group, quad q of the pair) ----
+    {
+      // Interval B: this wave's depthwise parameters out of Pd, depthwise of chunk c, then the next chunk's expand parameters -> Pe
+      // (requested in interval A; the expand is done with Pe).
+      v4i dwa[2][KT2];
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int mi = 0; mi < KT2; mi++) dwa[q][mi] = toeplitz_operand(*(const unsigned*)(Pd + 4 * (((cq0 + q) * KT2 + mi) * 64 + lane)), r & 3);
+      const int4 bq0 = *(const int4*)(Pd + 16 * (KT2 * 256) + 16 * cq0), bq1 = *(const int4*)(Pd + 16 * (KT2 * 256) + 16 * cq0 + 16);
+      const float4 mq0 = *(const float4*)(Pd + 16 * (KT2 * 256 + 16) + 16 * cq0), mq1 = *(const float4*)(Pd + 16 * (KT2 * 256 + 16) + 16 * cq0 + 16);
+      auto d_units = [&](auto full_c, auto u_c, auto pg_c) {
+        constexpr int U = decltype(u_c)::value, pg0 = decltype(pg_c)::value;
+        constexpr int FULL = decltype(full_c)::value;
+        const unsigned char* base[U];
+        int doff[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { base[u] = E + dbase[pg0 + u]; doff[u] = ddoff[pg0 + u]; }
+        v4i bv[U][2][KT2];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int mi = 0; mi < KT2; mi++) {
+#if XD2_KO_D >= 4
+              bv[u][q][mi] = (v4i){u, q, mi, doff[u]};
+#else
+              bv[u][q][mi] = *(const v4i*)(base[u] + q * a.EQS + mi * 2 * a.EYS);
+#endif
+            }
+        v4i acc[U][2];
+#pragma unroll
+        for (int u = 0; u < U; u++) { acc[u][0] = v4i_from(bq0); acc[u][1] = v4i_from(bq1); }
+#pragma unroll
+        for (int mi = 0; mi < KT2; mi++)
+#pragma unroll
+          for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+#if XD2_KO_D >= 3
+              asm volatile("" ::"v"(bv[u][q][mi]));
+#else
+              acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(dwa[q][mi], bv[u][q][mi], acc[u][q], 0, 0, 0);
+#endif
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#if XD2_KO_D >= 2
+          asm volatile("" ::"v"(acc[u][0]), "v"(acc[u][1]), "v"(doff[u]));
+#else
+          const unsigned v0 = rq_pack_b<FULL>(acc[u][0], mq0, a.rqd), v1 = rq_pack_b<FULL>(acc[u][1], mq1, a.rqd);
+#if XD2_KO_D >= 1
+          asm volatile("" ::"v"(v0), "v"(v1), "v"(doff[u]));
+#else
+          if (doff[u] >= 0) {
+            *(unsigned*)(D + doff[u]) = v0;
+            *(unsigned*)(D + doff[u] + a.PS) = v1;
+          }
+#endif
+#endif
+        }
+      };
+      auto d_walk = [&](auto full_c) {   // position groups in pairs (two groups x two quads = four independent MFMA chains), unrolled: register-indexed offsets
+        d_pair<0>(d_units, full_c, NPGo);
+      };
+      if (a.rqd.full) d_walk(std::integral_constant<int, 1>{}); else d_walk(std::integral_constant<int, 0>{});
+    }
+    put_pe();
+    __syncthreads();   // D complete, E free for the next chunk's expand, its expand parameters in Pe
+    XD2_STAMP(3 + 2 * (c - c_first));
+  }
+  copy_out(c_last - 1);
+  XD2_STAMP(2 + 2 * (c_last - c_first));
+}
