@@ -62,6 +62,41 @@ def test_every_tensor_bit_exact(model_path, frames, oracle_run, flags):
         assert np.array_equal(classes[b], oc)
 
 
+@pytest.mark.parametrize("env", [{"VBT_PW_VARIANT": "3"}, {"VBT_PW_VARIANT": "4"}, {"VBT_PW_VARIANT": "2"}, {"VBT_XD_VARIANT": "1"}, {"VBT_XD_VARIANT": "3"},
+                                 {"VBT_XD_VARIANT": "101"}, {"VBT_XD_VARIANT": "103"}, {"VBT_XD_VARIANT": "106", "VBT_PW_VARIANT": "4"}])
+def test_forced_kernel_variants_bit_exact(model_path, frames, oracle_run, env):
+    """Kernel variants the autotuner may or may not pick on a given day, forced through the test-only environment overrides (read
+    once per process, hence a child process per case): the large-K pointwise conv with its weights shared through LDS (3 / 4) or split
+    over the waves (2), and both forms of the expand + depthwise kernel (chunks per workgroup; 100 + n = the second form).  Every
+    materialised tensor and every detection must equal the oracle's."""
+    import os, subprocess, sys, tempfile, pickle
+    outs, tensors = oracle_run
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "in.pkl")
+        with open(src, "wb") as f:
+            pickle.dump((model_path, frames), f)
+        code = (
+            "import pickle, sys, numpy as np\n"
+            "from vbt_amd.interpreter import Interpreter\n"
+            "model, frames = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "B = len(frames)\n"
+            "it = Interpreter(model, max_batch=B, flags=8)\n"
+            "det = it.detect(frames)\n"
+            "ten = {t: it.read_tensor(t, B) for t in range(1, it.num_tensors() - 1) if it.materialized(t)}\n"
+            "pickle.dump((det, ten), open(sys.argv[2], 'wb'))\n")
+        dst = os.path.join(td, "out.pkl")
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+        subprocess.run([sys.executable, "-c", code, src, dst], check=True, cwd=root, env={**os.environ, **env}, timeout=300)
+        (boxes, scores, classes, counts), ten = pickle.load(open(dst, "rb"))
+    assert len(ten) > 60
+    for tid, got in ten.items():
+        for b in range(len(frames)):
+            assert np.array_equal(got[b], tensors[b][tid - 1]), f"tensor {tid} of frame {b} differs under {env}"
+    for b in range(len(frames)):
+        ob, os_, oc, on = outs[b]
+        assert counts[b] == on and np.array_equal(scores[b], os_) and np.array_equal(boxes[b], ob) and np.array_equal(classes[b], oc)
+
+
 def test_batch_tail_and_single_frame(model_path, frames, oracle_run):
     """B=1 (the reference's call shape) and a batch smaller than max_batch."""
     from vbt_amd.interpreter import Interpreter

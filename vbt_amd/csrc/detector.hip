@@ -304,6 +304,65 @@ __global__ __launch_bounds__(256) void pw_c_kernel(const int8_t* __restrict__ x,
   }
 }
 
+// variant D: large K, weights shared through LDS.  A workgroup owns 64 * MS pixels x one 64-channel block over the whole K; per
+// K-step each wave fetches ONE 16-byte weight operand per lane (a quarter of the block's 4 KB) into a double-buffered LDS copy and
+// its own MS activation operands into registers, a step ahead, then reads the four weight tiles back from LDS (256 B/clk/CU
+// against the 64 B/clk of the vector-memory path) for 4 * MS MFMAs.  Variants B and C pull every weight operand through the
+// vector-memory path once per wave - 4 loads of 1 KB per K-step and wave, 16 address cycles each on the CU's one address unit -
+// which is what they saturate (tools/probes: MFMA 5 % busy, three quarters of the wave-cycles waiting).  One barrier per K-step;
+// no load is issued under a condition (the prefetch index is clamped) so that the compiler's vmcnt waits stay exact.
+template <int MS>
+__global__ __launch_bounds__(256) void pw_d_kernel(const int8_t* __restrict__ x, const v4i* __restrict__ wp, Epi e, ResArgs ra,
+                                                   int8_t* __restrict__ out, long M, int K, int KS, int N, int NB) {
+  __shared__ v4i wbuf[2][4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * (16 * MS);
+  const int nb = blockIdx.y;
+  const int8_t* p[MS];
+  EpiRegs er[MS];
+#pragma unroll
+  for (int s = 0; s < MS; s++) {
+    const long mc = min(m0 + 16 * s + r, M - 1);
+    p[s] = x + mc * K + 16 * g;
+    load_epi(er[s], e, ra, mc, N, nb, g);
+  }
+  v4i acc[MS][4];
+#pragma unroll
+  for (int s = 0; s < MS; s++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[s][t] = (v4i){0, 0, 0, 0};
+  const v4i* w = wp + ((long)nb * KS * 4 + wave) * 64 + lane;   // this wave's tile of K-step 0; a K-step is 4 * 64 operands further
+  v4i wreg = w[0];
+  v4i a_cur[MS], a_nxt[MS];
+#pragma unroll
+  for (int s = 0; s < MS; s++) a_cur[s] = ld16(p[s]);
+  wbuf[0][wave][lane] = wreg;
+  __syncthreads();
+  for (int ks = 0; ks < KS; ks++) {
+    const int kn = min(ks + 1, KS - 1);
+    wreg = w[(long)kn * 4 * 64];
+#pragma unroll
+    for (int s = 0; s < MS; s++) a_nxt[s] = ld16(p[s] + 64 * kn);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const v4i wv = wbuf[ks & 1][t][lane];
+#pragma unroll
+      for (int s = 0; s < MS; s++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, a_cur[s], acc[s][t], 0, 0, 0);
+    }
+    wbuf[(ks + 1) & 1][wave][lane] = wreg;
+#pragma unroll
+    for (int s = 0; s < MS; s++) a_cur[s] = a_nxt[s];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int s = 0; s < MS; s++) {
+    const long m = m0 + 16 * s + r;
+    if (m < M) store_tile_e(acc[s], er[s], e, ra, out, m, N, nb, g);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // stem: 3x3 stride-2 conv on the uint8 frame as one 16x16x32 MFMA K-step.  The 27 taps are
 // laid out per lane group g: g<3 -> the first 8 bytes (px0 RGB, px1 RGB, px2 RG) of kernel row g,
@@ -2464,6 +2523,9 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       if (s.res_op >= 0) ra.res = TP(m->ops[s.res_op].inputs[1]);   // ADD(conv output, skip): planner guarantees the order
       long M = (long)B * tpo.h * tpo.w;
       int K = ti.c, N = tpo.c;
+      // VBT_PW_VARIANT (tests): the kernel variant of every pointwise conv with K > 256, whatever the plan says
+      static const int pw_force = getenv("VBT_PW_VARIANT") ? atoi(getenv("VBT_PW_VARIANT")) : -100;
+      const int pw_variant = (pw_force != -100 && s.KS64 > 4) ? pw_force : s.variant;
       if (s.KS64 <= 4) {
         int MS = s.variant >= 0 ? (s.variant & 1) + 1 : (M >= 32768 ? 2 : 1);
         long waves = (M + 16 * MS - 1) / (16 * MS);
@@ -2479,7 +2541,12 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
           case 3: launch_pw_a<3>(MS, grid, st, x, s.wp64, e, ra, out, M, K, N, s.NB, nb_per_y); break;
           default: launch_pw_a<4>(MS, grid, st, x, s.wp64, e, ra, out, M, K, N, s.NB, nb_per_y); break;
         }
-      } else if (s.variant == 2) {  // split-K over the 4 waves of a workgroup
+      } else if (pw_variant == 3 || pw_variant == 4) {  // weights shared through LDS, 64 (variant 3) or 128 (variant 4) pixels per workgroup
+        const int ms = pw_variant - 2;
+        dim3 grid((unsigned)((M + 64 * ms - 1) / (64 * ms)), (unsigned)s.NB);
+        if (ms == 2) pw_d_kernel<2><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+        else pw_d_kernel<1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+      } else if (pw_variant == 2) {  // split-K over the 4 waves of a workgroup
         // one 64-channel block per workgroup (16 KB of LDS for the cross-wave reduction, twice the workgroups) rather than two
         // (32 KB): +1.4 % end to end with three forwards in flight - the workgroups of one launch then fit the CUs in one round
         static const int nbt_max = getenv("VBT_PWC_NBT") ? atoi(getenv("VBT_PWC_NBT")) : 1;
@@ -2681,22 +2748,26 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       const OpRec& eop = m->ops[s.e_op];
       const OpRec& dop = m->ops[s.d_op];
       // variant: chunks per workgroup on the first form of the kernel, 100 + chunks per workgroup on the second; -1: heuristic default
-      if (s.xd2_ok && (s.variant >= 100 || s.variant < 0)) {
+      // VBT_XD_VARIANT (tests): that variant for every step that supports it, whatever the plan says
+      static const int xd_force = getenv("VBT_XD_VARIANT") ? atoi(getenv("VBT_XD_VARIANT")) : -100;
+      int variant = s.variant;
+      if (xd_force != -100 && (xd_force < 100 || s.xd2_ok)) variant = std::min(xd_force, (xd_force >= 100 ? 100 : 0) + s.xd.nchunks);
+      if (s.xd2_ok && (variant >= 100 || variant < 0)) {
         ExpDw2Args a = s.xd2;
         a.x = TP(eop.inputs[0]);
         a.out = out;
-        a.cpw = s.variant >= 100 ? s.variant - 100 : std::max(1, (a.nchunks * a.nbands * B + 1023) / 1024);   // default: about four workgroups per CU
+        a.cpw = variant >= 100 ? variant - 100 : std::max(1, (a.nchunks * a.nbands * B + 1023) / 1024);   // default: about four workgroups per CU
         a.cpw = std::min(a.cpw, a.nchunks);
         const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
         const int rc = launch_expdw2(a, dop.k, (a.Cin + 63) / 64, s.xd2_gpw, (unsigned)(B * ngroups * a.nbands), s.xd2_lds, st);
         if (rc) return rc;
         break;
       }
-      if (s.variant >= 100) { set_error("expand + depthwise: plan asks for the second kernel form on a step that does not support it"); return VBT_ERR_ARG; }
+      if (variant >= 100) { set_error("expand + depthwise: plan asks for the second kernel form on a step that does not support it"); return VBT_ERR_ARG; }
       ExpDwArgs a = s.xd;
       a.x = TP(eop.inputs[0]);
       a.out = out;
-      a.cpw = s.variant > 0 ? s.variant : std::max(1, (a.nchunks * a.nbands * B + 511) / 512);   // default: about two workgroups per CU
+      a.cpw = variant > 0 ? variant : std::max(1, (a.nchunks * a.nbands * B + 511) / 512);   // default: about two workgroups per CU
       const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
       const int KS64 = (a.Cin + 63) / 64;
       dim3 grid((unsigned)(B * ngroups * a.nbands));
@@ -2799,7 +2870,7 @@ static void autotune(vbt_model* m) {
         } else if (st.family == F_PW && st.KS64 <= 4) {
           cand = {0, 1};
         } else if (st.family == F_PW) {
-          cand = {-1, 2};
+          cand = {-1, 2, 3, 4};
         } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
           cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
           if (image_geom(m, st).ok) cand.push_back(5);  // one workgroup per image
