@@ -1975,7 +1975,7 @@ static int make_expdw2(vbt_model* m, int e_op, int d_op, Step* s, const std::vec
   const ExpDwArgs& a1 = s->xd;
   s->xd2_ok = false;
   const int KS64 = (a1.Cin + 63) / 64;
-  if (!enabled || dop.stride != 1 || (dop.k != 3 && dop.k != 5) || a1.Cin % 16 != 0 || KS64 < 2 || KS64 > 4) return VBT_OK;
+  if (!enabled || dop.stride != 1 || (dop.k != 3 && dop.k != 5) || a1.Cin % 8 != 0 || KS64 < 2 || KS64 > 4) return VBT_OK;
   const ExpDw2Geom geo = expdw2_choose(a1.H, a1.W, a1.OH, a1.OW, dop.k, a1.pad_t, KS64);
   if (!geo.ok) return VBT_OK;
   ExpDw2Args& a = s->xd2;

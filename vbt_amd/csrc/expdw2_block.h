@@ -22,7 +22,7 @@
 //     vector-memory instructions per wave and chunk - 8 waves x 22 x 16 address cycles = 2800 cycles of the CU's one address path,
 //     the fixed cost the stage stamps showed in every interval.
 //   * LDS: E 39 KB + D 26 KB at 20x20 (was 120 KB): two workgroups per CU, so one's expand overlaps the other's depthwise.
-// Stride-2 blocks and inputs whose channel count is not a multiple of 16 stay on expdw_block.h.
+// Stride-2 blocks and inputs whose channel count is not a multiple of 8 stay on expdw_block.h.
 #pragma once
 #include <type_traits>
 
@@ -118,8 +118,12 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
       const int p = (wq + 4 * i) * 16 + r, pc = min(p, HW - 1);
 #pragma unroll
       for (int ks = 0; ks < KS64; ks++) {
-        const int k0 = 64 * ks + 16 * g;   // Cin % 16 == 0: a K slice lies inside the pixel's channels or wholly in the zero-weight padding
-        xin[i][ks] = k0 < a.Cin ? *(const v4i*)(xb + (long)pc * a.Cin + k0) : (v4i){0, 0, 0, 0};
+        // a K slice lies inside the pixel's channels, straddles their end (Cin % 16 == 8: the bytes past it are the next pixel's - or
+        // the arena's slack - and meet zero weights) or lies wholly in the zero-weight padding (not loaded); 8-byte aligned when Cin % 16 == 8
+        const int k0 = 64 * ks + 16 * g;
+        v4i v = {0, 0, 0, 0};
+        if (k0 < a.Cin) __builtin_memcpy(&v, xb + (long)pc * a.Cin + k0, 16);
+        xin[i][ks] = v;
       }
       const int py = fdiv_small(pc, rcp_w), px = pc - py * a.W;
       eoff[i] = p < HW ? (py + erow0) * a.EYS + (px + a.pad_l) * 4 + (8 * tp + g) * a.EQS : -1;
