@@ -14,12 +14,22 @@
 // 16 wavefronts; both stages on the 16x16x64 int8 MFMA (depthwise as a diagonal-embedded matrix product, four taps per
 // instruction: three instructions for 3x3).  Arithmetic identical to the per-op kernels.
 #pragma once
+#include <type_traits>
 
 #ifndef VBT_BD_WAVES
 #define VBT_BD_WAVES 16
 #endif
 constexpr int BD_WAVES = VBT_BD_WAVES, BD_THREADS = 64 * BD_WAVES;
+constexpr int BD_LIT = 3;           // lane-iterations of the load stage whose global loads are in flight together (plain input)
+constexpr int BD_LIT_NODE = 1;      // the same for a node's source loads (up to three 16-byte loads per iteration; registers: the head layers share this kernel)
 constexpr int BD_WP_TAIL = 1024;   // bias (512 B) | multipliers (512 B) behind the projection weights in LDS
+
+// Developer build (tools/probes/bd_probe.hip): s_memtime stamps of wave 0 at the stage boundaries of every workgroup.
+#ifdef VBT_BD_PROF
+#define BD_STAMP(k) do { if (threadIdx.x == 0) a.prof[(long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BD_STAMP(k) do { } while (0)
+#endif
 
 struct BandArgs {
   const int8_t* x;   // [B][H][W][C] (plain input; unused when n_src > 0)
@@ -41,6 +51,9 @@ struct BandArgs {
   const int8_t* src[3];
   int sh[3], sw[3], smode[3], spt[3], spl[3];
   AddQ sumq, preq;
+#ifdef VBT_BD_PROF
+  unsigned long long* prof;
+#endif
 };
 
 __device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long b, int iy, int ix, int cd, bool up2) {
@@ -69,6 +82,39 @@ __device__ __forceinline__ unsigned band_source4(const BandArgs& a, int j, long 
   return (lo | (hi << 8)) ^ 0x80808080u;
 }
 
+// the same for 16 channels (4 dwords) of one pixel: one address computation per source and pixel instead of one per dword
+__device__ __forceinline__ uint4 band_source16(const BandArgs& a, int j, long b, int iy, int ix, int sg, bool up2) {
+  const int C = a.C;
+  const int8_t* sb = a.src[j] + b * (long)a.sh[j] * a.sw[j] * C + 16 * sg;
+  if (a.smode[j] == 0) return *(const uint4*)(sb + (iy * a.sw[j] + ix) * C);
+  if (a.smode[j] == 1) {
+    int yy, xx;
+    if (up2) { yy = iy >> 1; xx = ix >> 1; }
+    else { yy = (iy * a.sh[j]) / a.H; xx = (ix * a.sw[j]) / a.W; }
+    return *(const uint4*)(sb + (yy * a.sw[j] + xx) * C);
+  }
+  unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};   // 3x3/2 max pool on the u8 image of the bytes (out-of-map taps = -128)
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++) {
+    const int yy = iy * 2 + ky - a.spt[j], yc = min(max(yy, 0), a.sh[j] - 1);
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      const int xx = ix * 2 + kx - a.spl[j], xc = min(max(xx, 0), a.sw[j] - 1);
+      const uint4 t4 = *(const uint4*)(sb + (yc * a.sw[j] + xc) * C);
+      const bool in = yy == yc && xx == xc;
+      const unsigned tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const unsigned t = in ? (tt[d] ^ 0x80808080u) : 0u;
+        lo[d] = pk_max_u16(lo[d], t & 0x00FF00FFu);
+        hi[d] = pk_max_u16(hi[d], (t >> 8) & 0x00FF00FFu);
+      }
+    }
+  }
+  return make_uint4((lo[0] | (hi[0] << 8)) ^ 0x80808080u, (lo[1] | (hi[1] << 8)) ^ 0x80808080u, (lo[2] | (hi[2] << 8)) ^ 0x80808080u,
+                    (lo[3] | (hi[3] << 8)) ^ 0x80808080u);
+}
+
 // NW waves per workgroup: 16 for a BiFPN node (one or two workgroups per image: the per-wave chain of units must be short), 8 for
 // the head layers (1280+ bands per launch: 16-wave workgroups fill every wave slot of a CU with two of them, so a third forward
 // in flight cannot co-reside; 8 waves on bands of <= 240 pixels interleave twice as many phases - +1.3 % end to end).
@@ -88,6 +134,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   unsigned char* WP = D + (((a.rows * a.W + 15) >> 4) << 4) * CS;   // NT x KS KB of weights | 512 B bias | 512 B mult
   const int NT = (a.Cout + 15) >> 4, KS = C64 ? 1 : a.KS, NCG = C64 ? 4 : a.NCG;
   unsigned char* WB = WP + NT * KS * 1024;
+  BD_STAMP(0);
 
   // ---- stage L: band + border -> T0; projection weights / bias / multipliers -> LDS ----
   for (int i = tid; i < NT * KS * 64; i += nthreads) *(v4i*)(WP + 16 * i) = a.wp[i];
@@ -96,10 +143,54 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const float rcp_pw = frcp(PW);
   if (a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
-    const int ndp = C64 ? 16 : CS >> 2, nd = C >> 2;   // dwords per pixel visited (Lite0: the 64 real channels only) / of real channels
+    if constexpr (C64) {
+      // 16 channels of one pixel per lane-iteration (the stage used to walk dwords: four times the address arithmetic and four
+      // times the dependent rounds of global loads - it was two thirds of a node kernel's time, tools/probes/bd_probe.hip); the
+      // source loads of an iteration are all requested before its sums are formed
+      const int total = NPh * 4;
+      for (int i0 = tid; i0 < total; i0 += BD_LIT_NODE * nthreads) {
+        uint4 us[BD_LIT_NODE][3];
+        int pofs[BD_LIT_NODE];   // LDS byte offset of the piece, -1: past the band; bit 30: outside the image (zero point)
+#pragma unroll
+        for (int k = 0; k < BD_LIT_NODE; k++) {
+          const int i = i0 + k * nthreads;
+          const int p = i >> 2, sg = i & 3;
+          const int hy = fdiv_small(min(p, NPh - 1), rcp_pw), hx = p - hy * PW;
+          const int iy = y0 + hy - 1, ix = hx - 1;
+          const bool in = i < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          pofs[k] = i < total ? (p * 80 + 16 * sg) | (in ? 0 : (1 << 30)) : -1;
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            us[k][j] = make_uint4(0u, 0u, 0u, 0u);
+            if (j < a.n_src && in) us[k][j] = band_source16(a, j, b, iy, ix, sg, up2[j]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < BD_LIT_NODE; k++) {
+          if (pofs[k] < 0) continue;
+          uint4 v = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
+          if (!(pofs[k] >> 30)) {
+            const unsigned u0[4] = {us[k][0].x, us[k][0].y, us[k][0].z, us[k][0].w}, u1[4] = {us[k][1].x, us[k][1].y, us[k][1].z, us[k][1].w},
+                           u2[4] = {us[k][2].x, us[k][2].y, us[k][2].z, us[k][2].w};
+            unsigned o[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+              if (a.chain == 0) o[d] = addq4(u0[d], u1[d], a.sumq);
+              else {
+                const unsigned pp = addq4(u0[d], u1[d], a.preq);
+                o[d] = a.chain == 1 ? addq4(pp, u2[d], a.sumq) : addq4(u2[d], pp, a.sumq);
+              }
+            }
+            v = make_uint4(o[0], o[1], o[2], o[3]);
+          }
+          *(uint4*)(T0 + (pofs[k] & 0xFFFFFF)) = v;
+        }
+      }
+    } else {
+    const int ndp = CS >> 2, nd = C >> 2;   // dwords per pixel visited / of real channels
     const float rcp_ndp = frcp(ndp);
     for (int i = tid; i < NPh * ndp; i += nthreads) {   // 4 channels per lane-iteration
-      const int p = C64 ? i >> 4 : fdiv_small(i, rcp_ndp), cd = i - p * ndp;
+      const int p = fdiv_small(i, rcp_ndp), cd = i - p * ndp;
       const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
       const int iy = y0 + hy - 1, ix = hx - 1;
       unsigned v = a.zx4;
@@ -116,17 +207,28 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       }
       *(unsigned*)(T0 + p * CS + 4 * cd) = v;
     }
+    }
   } else {
     const int8_t* xb = a.x + b * (long)a.H * a.W * C;
     if constexpr (C64) {
       const uint4 z4 = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
-      for (int i = tid; i < NPh * 4; i += nthreads) {    // 16 bytes per lane-iteration
-        const int p = i >> 2, sg = i & 3;
-        const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
-        const int iy = y0 + hy - 1, ix = hx - 1;
-        uint4 v = z4;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint4*)(xb + (iy * a.W + ix) * 64 + 16 * sg);
-        *(uint4*)(T0 + p * 80 + 16 * sg) = v;
+      const int total = NPh * 4;
+      for (int i0 = tid; i0 < total; i0 += BD_LIT * nthreads) {    // 16 bytes per lane-iteration, BD_LIT loads in flight
+        uint4 v[BD_LIT];
+        int pofs[BD_LIT];
+#pragma unroll
+        for (int k = 0; k < BD_LIT; k++) {
+          const int i = i0 + k * nthreads;
+          const int p = i >> 2, sg = i & 3;
+          const int hy = fdiv_small(min(p, NPh - 1), rcp_pw), hx = p - hy * PW;
+          const int iy = y0 + hy - 1, ix = hx - 1;
+          pofs[k] = i < total ? p * 80 + 16 * sg : -1;
+          v[k] = z4;
+          if (i < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v[k] = *(const uint4*)(xb + (iy * a.W + ix) * 64 + 16 * sg);
+        }
+#pragma unroll
+        for (int k = 0; k < BD_LIT; k++)
+          if (pofs[k] >= 0) *(uint4*)(T0 + pofs[k]) = v[k];
       }
     } else {
     const int ngp = CS >> 3, ng = C >> 3;              // 8-byte granules per LDS row / of real channels
@@ -158,18 +260,42 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   }
   const float rcp_w = frcp(a.W);
   __syncthreads();
-  // ---- stage D: depthwise; unit = (output pixel group, channel group cg) ----
-  if (sub < nsub)
-    for (int pg = sub; pg < NPG; pg += nsub) {
-      const int slot = pg * 16 + r, sc = min(slot, NPo - 1);
-      const int py = fdiv_small(sc, rcp_w), px = sc - py * a.W;
-      const unsigned char* pb = T0 + (py * PW + px) * CS + 16 * cg;
-      v4i acc = v4i_from(bq);
+  BD_STAMP(1);
+  // ---- stage D: depthwise; unit = (output pixel group, channel group cg).  Two units of a wave in flight: their operand reads are
+  // requested together and their MFMA chains interleave (one unit at a time, every MFMA waited for the one before it and every
+  // unit for its own LDS round trip) ----
+  if (sub < nsub) {
+    auto d_units = [&](auto u_c, int pg0) {
+      constexpr int U = decltype(u_c)::value;
+      const unsigned char* pb[U];
+      int slot[U];
 #pragma unroll
-      for (int m = 0; m < 3; m++) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wdv[m], *(const v4i*)(pb + tapoff[m]), acc, 0, 0, 0);
-      *(unsigned*)(D + slot * CS + 16 * cg + 4 * g) = rq_pack_b(acc, mu, a.rqd);
-    }
+      for (int u = 0; u < U; u++) {
+        slot[u] = (pg0 + u * nsub) * 16 + r;
+        const int sc = min(slot[u], NPo - 1);
+        const int py = fdiv_small(sc, rcp_w);
+        pb[u] = T0 + (sc + 2 * py) * CS + 16 * cg;   // (py * PW + px) with PW = W + 2 and px = sc - py * W
+      }
+      v4i bv[U][3], acc[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int m = 0; m < 3; m++) bv[u][m] = *(const v4i*)(pb[u] + tapoff[m]);
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = v4i_from(bq);
+#pragma unroll
+      for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wdv[m], bv[u][m], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; u++) *(unsigned*)(D + slot[u] * CS + 16 * cg + 4 * g) = rq_pack_b(acc[u], mu, a.rqd);
+    };
+    int pg = sub;
+    for (; pg + nsub < NPG; pg += 2 * nsub) d_units(std::integral_constant<int, 2>{}, pg);
+    if (pg < NPG) d_units(std::integral_constant<int, 1>{}, pg);
+  }
   __syncthreads();
+  BD_STAMP(2);
   // ---- stage P: projection; unit = (pixel group, 16-channel output tile) ----
   const int NU = NPG * NT;
   const float rcp_nt = frcp(NT);
@@ -185,18 +311,32 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
           if (c0 + j < a.Cout) o[j] = (int8_t)(d >> (8 * j));
     }
   };
-  if (NT == 4 && KS == 1) {
+  if (NT == 4 && KS == 1 && a.Cout == 64) {
     // 64 -> 64 channels (every Lite0 layer but the heads' last): unit u = wave + 16 i is tile t = wave & 3 of pixel group
     // (wave >> 2) + 4 i, so the wave's weights / bias / multipliers are loop invariants
     const int t = wave & 3, c0 = 16 * t + 4 * g;
     const v4i wv = *(const v4i*)(WP + (t * 64 + lane) * 16);
     const int4 bb = *(const int4*)(WB + 4 * c0);
     const float4 mm = *(const float4*)(WB + 512 + 4 * c0);
-    for (int pg = wave >> 2; pg < NPG; pg += nwaves / 4) {
-      v4i acc = v4i_from(bb);
-      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, *(const v4i*)(D + (pg * 16 + r) * CS + 16 * g), acc, 0, 0, 0);
-      store_unit(pg, t, acc, mm);
-    }
+    // two units in flight, the output address one 64-bit multiply-add per unit from a base formed once
+    int8_t* ob = a.out + ((b * a.H + y0) * (long)a.W) * a.Cout + c0;   // the band's pixels are contiguous: (y0 + py) * W + px = y0 * W + slot
+    auto p_units = [&](auto u_c, int pg0) {
+      constexpr int U = decltype(u_c)::value;
+      v4i dv[U], acc[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) dv[u] = *(const v4i*)(D + ((pg0 + u * (nwaves / 4)) * 16 + r) * CS + 16 * g);
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, dv[u], v4i_from(bb), 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int slot = (pg0 + u * (nwaves / 4)) * 16 + r;
+        const unsigned d = rq_pack_b(acc[u], mm, a.rqp);
+        if (slot < NPo) *(unsigned*)(ob + (long)slot * a.Cout) = d;
+      }
+    };
+    int pg = wave >> 2;
+    for (; pg + (nwaves / 4) < NPG; pg += 2 * (nwaves / 4)) p_units(std::integral_constant<int, 2>{}, pg);
+    if (pg < NPG) p_units(std::integral_constant<int, 1>{}, pg);
   } else {
     for (int u = wave; u < NU; u += nwaves) {
       const int pg = fdiv_small(u, rcp_nt), t = u - pg * NT;
@@ -208,6 +348,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       store_unit(pg, t, acc, *(const float4*)(WB + 512 + 4 * c0));
     }
   }
+  BD_STAMP(3);
 }
 
 // Several problems in one grid (the same head layer on all pyramid levels of both heads): the problem list lives in HBM.
