@@ -953,7 +953,7 @@ struct Step {
   ExpDwArgs xd;
   ExpDw2Args xd2;              // the same step on the second form of the kernel (expdw2_block.h); variant 100 + cpw runs it
   bool xd2_ok = false;
-  int xd2_lds = 0, xd2_gpw = 0;
+  int xd2_lds = 0, xd2_gpw = 0, xd2_gpw16 = 0;   // input pixel groups per wave on 8 / 16 waves (0: that wave count is not available)
   // F_MBCONV on a low-resolution map: per-chunk weight records of the whole-image kernel (data == nullptr: not built)
   ImageBundle ib = {nullptr, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -1926,7 +1926,7 @@ static long xd2_read_cycles(int OHb, int XB, int EYS) {
     }
   return cycles;
 }
-struct ExpDw2Geom { bool ok; int nbands, brows, XB, EQS, EYS, e_bytes, PS, pe_off, pd_off, lds, gpw; };
+struct ExpDw2Geom { bool ok; int nbands, brows, XB, EQS, EYS, e_bytes, PS, pe_off, pd_off, lds, gpw, gpw16; };
 static ExpDw2Geom expdw2_geom(int H, int W, int OH, int OW, int k, int pad_t, int KS64, int nbands) {
   ExpDw2Geom g{};
   g.brows = (OH + nbands - 1) / nbands;
@@ -1955,7 +1955,11 @@ static ExpDw2Geom expdw2_geom(int H, int W, int OH, int OW, int k, int pad_t, in
   g.lds = g.pd_off + 16 * (KT2 * 256 + 32);
   const int npgi = (in_rows * W + 15) / 16, need = (npgi + 3) / 4;
   g.gpw = need <= 2 ? 2 : need <= 4 ? 4 : need <= 7 ? 7 : 0;
-  g.ok = g.gpw > 0 && g.lds <= 100 * 1024 && g.brows * g.XB <= 16 * XD2_NPG;
+  const int need16 = (npgi + 7) / 8;
+  g.gpw16 = need16 <= 1 ? 1 : need16 <= 2 ? 2 : need16 <= 4 ? 4 : 0;
+  if (g.gpw16 * KS64 > 8) g.gpw16 = 0;    // (the input operands a wave keeps: 4 registers each; beyond these the kernels spill)
+  if (g.gpw * KS64 > 21) g.gpw = 0;
+  g.ok = g.gpw > 0 && g.lds <= 100 * 1024 && g.brows * g.XB <= 16 * XD2_NPG && g.e_bytes < 65536 && 16 * g.PS < 65535;   // (16-bit LDS offsets in the kernel)
   return g;
 }
 static ExpDw2Geom expdw2_choose(int H, int W, int OH, int OW, int k, int pad_t, int KS64) {
@@ -2018,6 +2022,7 @@ static int make_expdw2(vbt_model* m, int e_op, int d_op, Step* s, const std::vec
   s->xd2_ok = true;
   s->xd2_lds = geo.lds;
   s->xd2_gpw = geo.gpw;
+  s->xd2_gpw16 = geo.gpw16;
   return VBT_OK;
 }
 
@@ -2747,19 +2752,22 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
     case F_EXPDW: {
       const OpRec& eop = m->ops[s.e_op];
       const OpRec& dop = m->ops[s.d_op];
-      // variant: chunks per workgroup on the first form of the kernel, 100 + chunks per workgroup on the second; -1: heuristic default
+      // variant: chunks per workgroup on the first form of the kernel, 100 + chunks per workgroup on the second with 8 waves, 200 + chunks
+      // with 16 waves; -1: heuristic default
       // VBT_XD_VARIANT (tests): that variant for every step that supports it, whatever the plan says
       static const int xd_force = getenv("VBT_XD_VARIANT") ? atoi(getenv("VBT_XD_VARIANT")) : -100;
       int variant = s.variant;
-      if (xd_force != -100 && (xd_force < 100 || s.xd2_ok)) variant = std::min(xd_force, (xd_force >= 100 ? 100 : 0) + s.xd.nchunks);
+      if (xd_force != -100 && (xd_force < 100 || (s.xd2_ok && (xd_force < 200 || s.xd2_gpw16 > 0)))) variant = std::min(xd_force, xd_force / 100 * 100 + s.xd.nchunks);
       if (s.xd2_ok && (variant >= 100 || variant < 0)) {
+        if (variant >= 200 && s.xd2_gpw16 == 0) { set_error("expand + depthwise: plan asks for the 16-wave form on a step that does not support it"); return VBT_ERR_ARG; }
+        const int nw = (variant >= 200 || (variant < 0 && s.xd2_gpw16 > 0)) ? 16 : 8;
         ExpDw2Args a = s.xd2;
         a.x = TP(eop.inputs[0]);
         a.out = out;
-        a.cpw = variant >= 100 ? variant - 100 : std::max(1, (a.nchunks * a.nbands * B + 1023) / 1024);   // default: about four workgroups per CU
+        a.cpw = variant >= 100 ? variant % 100 : std::max(1, (a.nchunks * a.nbands * B + 1023) / 1024);   // default: about four workgroups per CU
         a.cpw = std::min(a.cpw, a.nchunks);
         const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
-        const int rc = launch_expdw2(a, dop.k, (a.Cin + 63) / 64, s.xd2_gpw, (unsigned)(B * ngroups * a.nbands), s.xd2_lds, st);
+        const int rc = launch_expdw2(a, dop.k, (a.Cin + 63) / 64, nw, nw == 16 ? s.xd2_gpw16 : s.xd2_gpw, (unsigned)(B * ngroups * a.nbands), s.xd2_lds, st);
         if (rc) return rc;
         break;
       }
@@ -2887,7 +2895,10 @@ static void autotune(vbt_model* m) {
             if (cpw <= st.xd.nchunks) cand.push_back(cpw);
           if (st.xd2_ok)
             for (int cpw : {1, 2, 3, 4, 6})
-              if (cpw <= st.xd.nchunks) cand.push_back(100 + cpw);
+              if (cpw <= st.xd.nchunks) {
+                cand.push_back(100 + cpw);
+                if (st.xd2_gpw16 > 0) cand.push_back(200 + cpw);
+              }
         }
         double best = 1e30;
         int bestv = -1;

@@ -26,19 +26,12 @@
 #pragma once
 #include <type_traits>
 
-#ifndef XD2_KO_D
-#define XD2_KO_D 0   // probe builds: knock-outs of the depthwise stage (1 no store, 2 no requantisation, 3 no MFMA, 4 no LDS read, 5 no address arithmetic)
-#endif
-#ifndef XD2_KO_E
-#define XD2_KO_E 0   // the same for the expand stage (1 no store, 2 no requantisation, 3 no MFMA)
-#endif
 #ifdef VBT_XD_PROF
 #define XD2_STAMP(k) do { if (tid == 0) a.prof[(long)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define XD2_STAMP(k) do { } while (0)
 #endif
 
-constexpr int XD2_WAVES = 8, XD2_THREADS = 64 * XD2_WAVES;
 
 struct ExpDw2Args {
   const int8_t* x;   // [B][H][W][Cin]
@@ -83,9 +76,15 @@ __device__ __forceinline__ void d_pair(F& d_units, FC full_c, int NPGo) {
   }
 }
 
-// KK: depthwise kernel size (stride 1); KS64: 64-channel K steps of the expand; GPW: input pixel groups a wave owns (>= ceil(pixel groups / 4))
-template <int KK, int KS64, int GPW>
-__global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
+// KK: depthwise kernel size (stride 1); KS64: 64-channel K steps of the expand; NW: waves per workgroup; GPW: input pixel groups a wave
+// owns (>= ceil(pixel groups / (NW / 2))).
+// NW = 8: a wave expands a pair of 16-channel tiles on up to 7 pixel groups and runs the depthwise of two channel quads - 180-240
+// registers, two waves per SIMD.  NW = 16: a tile pair on up to 4 pixel groups, one quad - the compiler has to stay within 128
+// registers, four waves per SIMD: the vector ALU issues a wave-instruction every 2.8 cycles instead of 3.5
+// (tools/probes/valu_rate.hip) and a wave's LDS / MFMA waits are covered by three others instead of one.
+template <int KK, int KS64, int NW, int GPW>
+__global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
+  constexpr int XD2_THREADS = 64 * NW, HW2 = NW / 2, QW = 16 / NW;   // threads; waves per tile pair; channel quads per wave in the depthwise
   extern __shared__ __attribute__((aligned(16))) unsigned char xd2_smem[];
   constexpr int KT2 = (KK + 1) / 2;   // depthwise MFMAs per unit: two kernel rows each
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
   const int c_first = grp * a.cpw, c_last = min(c_first + a.cpw, a.nchunks);
 
   // ---- expand stage, per-lane constants: wave = (tile pair tp, pixel group phase wq); lane (r, g) = pixel r of a group, K slice g ----
-  const int tp = wave >> 2, wq = wave & 3;
+  const int tp = wave / HW2, wq = wave % HW2;
   v4i xin[GPW][KS64];
   int eoff[GPW];   // E byte offset of this lane's dword for tile 2 tp (channel quad 8 tp + g), -1: no such pixel
   {
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
     const float rcp_w = frcp(a.W);
 #pragma unroll
     for (int i = 0; i < GPW; i++) {
-      const int p = (wq + 4 * i) * 16 + r, pc = min(p, HW - 1);
+      const int p = (wq + HW2 * i) * 16 + r, pc = min(p, HW - 1);
 #pragma unroll
       for (int ks = 0; ks < KS64; ks++) {
         // a K slice lies inside the pixel's channels, straddles their end (Cin % 16 == 8: the bytes past it are the next pixel's - or
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
   };
   fetch_params(c_first);
   asm volatile("" ::: "memory");   // the compiler otherwise sinks loads to their first use and waits for them there
-  const int cq0 = 2 * wave;        // depthwise stage: this wave's channel quads are cq0, cq0 + 1
+  const int cq0 = QW * wave;       // depthwise stage: this wave's channel quads are cq0 .. cq0 + QW - 1
   // E <- zero point: border, rows outside the image and the padding columns keep it (the expand writes real pixels only)
   {
     const uint4 z4 = make_uint4(a.zeb, a.zeb, a.zeb, a.zeb);
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
   // ---- depthwise stage, per-lane constants: wave owns channel quads 2 wave, 2 wave + 1; lane (r, g) = position r of a group, K slice g ----
   // E byte offset of this lane's operand (kernel rows 0 / 1, column half g & 1, quad cq0) and D byte offset of its output dword for
   // every position group, once per kernel: the stage itself then has no address arithmetic (it was a quarter of its vector instructions)
-  int dbase[XD2_NPG], ddoff[XD2_NPG];   // ddoff -1: no such output pixel
+  unsigned dofs[XD2_NPG];   // low half: E offset (< 64 KB); high half: D offset (< 64 KB), 0xffff: no such output pixel
   {
     const int gofs = (g >> 1) * a.EYS + 16 * (g & 1) + cq0 * a.EQS;
     const float rcp_xb = frcp(a.XB);
@@ -171,9 +170,8 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
     for (int pg = 0; pg < XD2_NPG; pg++) {
       const int n = pg * 16 + r, nc = min(n, NPOS - 1);
       const int y = fdiv_small(nc, rcp_xb), xk = nc - y * a.XB;
-      dbase[pg] = y * a.EYS + xk * 16 + gofs;
       const int ox = 4 * xk + g;
-      ddoff[pg] = (n < NPOS && ox < a.OW) ? (y * a.OW + ox) * 4 + cq0 * a.PS : -1;
+      dofs[pg] = (unsigned)(y * a.EYS + xk * 16 + gofs) | ((n < NPOS && ox < a.OW) ? (unsigned)((y * a.OW + ox) * 4 + cq0 * a.PS) << 16 : 0xffff0000u);
     }
   }
   // ---- copy-out: D (quad-planar) -> the depthwise output tensor, 16 bytes per lane ----
@@ -198,48 +196,29 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
     fetch_params(min(c + 1, c_last - 1));   // two intervals ahead of put_pe: a depthwise stage can be shorter than a round trip to memory
     asm volatile("" ::: "memory");
     if (c > c_first) copy_out(c - 1);
-    v4i ew[2][KS64];
-    int4 eb[2];
-    float4 em[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; tt++) {
-#pragma unroll
-      for (int ks = 0; ks < KS64; ks++) ew[tt][ks] = *(const v4i*)(Pe + 16 * ((ks * 4 + 2 * tp + tt) * 64 + lane));
-      eb[tt] = *(const int4*)(Pe + 16 * (KS64 * 256) + 4 * (16 * (2 * tp + tt) + 4 * g));
-      em[tt] = *(const float4*)(Pe + 16 * (KS64 * 256 + 16) + 4 * (16 * (2 * tp + tt) + 4 * g));
-    }
     // ---- stage E: expand chunk c; unit = (pixel group i, tile tt of the pair); every B operand is in registers ----
     {
       auto e_stage = [&](auto full_c) {
         constexpr int FULL = decltype(full_c)::value;
 #pragma unroll
         for (int tt = 0; tt < 2; tt++) {
+          // this tile's weights / bias / multipliers out of Pe (one tile at a time: registers - the 16-wave form lives within 128)
+          v4i ew[KS64];
+#pragma unroll
+          for (int ks = 0; ks < KS64; ks++) ew[ks] = *(const v4i*)(Pe + 16 * ((ks * 4 + 2 * tp + tt) * 64 + lane));
+          const int4 eb = *(const int4*)(Pe + 16 * (KS64 * 256) + 4 * (16 * (2 * tp + tt) + 4 * g));
+          const float4 em = *(const float4*)(Pe + 16 * (KS64 * 256 + 16) + 4 * (16 * (2 * tp + tt) + 4 * g));
           v4i acc[GPW];
 #pragma unroll
-          for (int i = 0; i < GPW; i++) acc[i] = v4i_from(eb[tt]);
+          for (int i = 0; i < GPW; i++) acc[i] = v4i_from(eb);
 #pragma unroll
           for (int ks = 0; ks < KS64; ks++)
 #pragma unroll
-            for (int i = 0; i < GPW; i++) {
-#if XD2_KO_E >= 3
-              { const v4i xv = xin[i][ks], wv = ew[tt][ks]; asm volatile("" ::"v"(xv), "v"(wv)); }
-#else
-              acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ew[tt][ks], xin[i][ks], acc[i], 0, 0, 0);
-#endif
-            }
+            for (int i = 0; i < GPW; i++) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ew[ks], xin[i][ks], acc[i], 0, 0, 0);
 #pragma unroll
           for (int i = 0; i < GPW; i++) {
-            const int eo = eoff[i];
-#if XD2_KO_E >= 2
-            asm volatile("" ::"v"(acc[i]), "v"(eo));
-#else
-            const unsigned val = rq_pack_b<FULL>(acc[i], em[tt], a.rqe);
-#if XD2_KO_E >= 1
-            asm volatile("" ::"v"(val), "v"(eo));
-#else
-            if (eo >= 0) *(unsigned*)(E + eo + tt * 4 * a.EQS) = val;
-#endif
-#endif
+            const unsigned val = rq_pack_b<FULL>(acc[i], em, a.rqe);
+            if (eoff[i] >= 0) *(unsigned*)(E + eoff[i] + tt * 4 * a.EQS) = val;
           }
         }
       };
@@ -251,66 +230,53 @@ __global__ __launch_bounds__(XD2_THREADS) void expdw2_kernel(ExpDw2Args a) {
     {
       // Interval B: this wave's depthwise parameters out of Pd, depthwise of chunk c, then the next chunk's expand parameters -> Pe
       // (requested in interval A; the expand is done with Pe).
-      v4i dwa[2][KT2];
+      v4i dwa[QW][KT2];
+      int4 bq[QW];
+      float4 mq[QW];
 #pragma unroll
-      for (int q = 0; q < 2; q++)
+      for (int q = 0; q < QW; q++) {
 #pragma unroll
         for (int mi = 0; mi < KT2; mi++) dwa[q][mi] = toeplitz_operand(*(const unsigned*)(Pd + 4 * (((cq0 + q) * KT2 + mi) * 64 + lane)), r & 3);
-      const int4 bq0 = *(const int4*)(Pd + 16 * (KT2 * 256) + 16 * cq0), bq1 = *(const int4*)(Pd + 16 * (KT2 * 256) + 16 * cq0 + 16);
-      const float4 mq0 = *(const float4*)(Pd + 16 * (KT2 * 256 + 16) + 16 * cq0), mq1 = *(const float4*)(Pd + 16 * (KT2 * 256 + 16) + 16 * cq0 + 16);
+        bq[q] = *(const int4*)(Pd + 16 * (KT2 * 256) + 16 * (cq0 + q));
+        mq[q] = *(const float4*)(Pd + 16 * (KT2 * 256 + 16) + 16 * (cq0 + q));
+      }
       auto d_units = [&](auto full_c, auto u_c, auto pg_c) {
         constexpr int U = decltype(u_c)::value, pg0 = decltype(pg_c)::value;
         constexpr int FULL = decltype(full_c)::value;
         const unsigned char* base[U];
         int doff[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { base[u] = E + dbase[pg0 + u]; doff[u] = ddoff[pg0 + u]; }
-        v4i bv[U][2][KT2];
+        for (int u = 0; u < U; u++) { base[u] = E + (dofs[pg0 + u] & 0xffffu); doff[u] = (int)(dofs[pg0 + u] >> 16); }
+        v4i bv[U][QW][KT2];
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int q = 0; q < 2; q++)
+          for (int q = 0; q < QW; q++)
 #pragma unroll
-            for (int mi = 0; mi < KT2; mi++) {
-#if XD2_KO_D >= 4
-              bv[u][q][mi] = (v4i){u, q, mi, doff[u]};
-#else
-              bv[u][q][mi] = *(const v4i*)(base[u] + q * a.EQS + mi * 2 * a.EYS);
-#endif
-            }
-        v4i acc[U][2];
+            for (int mi = 0; mi < KT2; mi++) bv[u][q][mi] = *(const v4i*)(base[u] + q * a.EQS + mi * 2 * a.EYS);
+        v4i acc[U][QW];
 #pragma unroll
-        for (int u = 0; u < U; u++) { acc[u][0] = v4i_from(bq0); acc[u][1] = v4i_from(bq1); }
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int q = 0; q < QW; q++) acc[u][q] = v4i_from(bq[q]);
 #pragma unroll
         for (int mi = 0; mi < KT2; mi++)
 #pragma unroll
           for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-#if XD2_KO_D >= 3
-              asm volatile("" ::"v"(bv[u][q][mi]));
-#else
-              acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(dwa[q][mi], bv[u][q][mi], acc[u][q], 0, 0, 0);
-#endif
-            }
+            for (int q = 0; q < QW; q++) acc[u][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(dwa[q][mi], bv[u][q][mi], acc[u][q], 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-#if XD2_KO_D >= 2
-          asm volatile("" ::"v"(acc[u][0]), "v"(acc[u][1]), "v"(doff[u]));
-#else
-          const unsigned v0 = rq_pack_b<FULL>(acc[u][0], mq0, a.rqd), v1 = rq_pack_b<FULL>(acc[u][1], mq1, a.rqd);
-#if XD2_KO_D >= 1
-          asm volatile("" ::"v"(v0), "v"(v1), "v"(doff[u]));
-#else
-          if (doff[u] >= 0) {
-            *(unsigned*)(D + doff[u]) = v0;
-            *(unsigned*)(D + doff[u] + a.PS) = v1;
+          unsigned v[QW];
+#pragma unroll
+          for (int q = 0; q < QW; q++) v[q] = rq_pack_b<FULL>(acc[u][q], mq[q], a.rqd);
+          if (doff[u] != 0xffff) {
+#pragma unroll
+            for (int q = 0; q < QW; q++) *(unsigned*)(D + doff[u] + q * a.PS) = v[q];
           }
-#endif
-#endif
         }
       };
-      auto d_walk = [&](auto full_c) {   // position groups in pairs (two groups x two quads = four independent MFMA chains), unrolled: register-indexed offsets
+      auto d_walk = [&](auto full_c) {   // position groups in pairs (two groups x QW quads: independent MFMA chains), unrolled: register-indexed offsets
         d_pair<0>(d_units, full_c, NPGo);
       };
       if (a.rqd.full) d_walk(std::integral_constant<int, 1>{}); else d_walk(std::integral_constant<int, 0>{});

@@ -52,22 +52,28 @@ int launch_expdw(const ExpDwArgs& a, int k, int stride, int KS64, unsigned grid_
   return VBT_OK;
 }
 
-template <int KK, int KS64, int GPW>
+template <int KK, int KS64, int NW, int GPW>
 static void launch_expdw2_t(const ExpDw2Args& a, unsigned grid, int lds_bytes, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw2_kernel<KK, KS64, GPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw2_kernel<KK, KS64, NW, GPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  expdw2_kernel<KK, KS64, GPW><<<dim3(grid), XD2_THREADS, lds_bytes, st>>>(a);
+  expdw2_kernel<KK, KS64, NW, GPW><<<dim3(grid), 64 * NW, lds_bytes, st>>>(a);
 }
 
-int launch_expdw2(const ExpDw2Args& a, int k, int KS64, int gpw, unsigned grid, int lds_bytes, hipStream_t st) {
-#define XD2_GPW(KK, KS)                                                     \
-  do {                                                                      \
-    if (gpw == 2) launch_expdw2_t<KK, KS, 2>(a, grid, lds_bytes, st);       \
-    else if (gpw == 4) launch_expdw2_t<KK, KS, 4>(a, grid, lds_bytes, st);  \
-    else launch_expdw2_t<KK, KS, 7>(a, grid, lds_bytes, st);                \
+int launch_expdw2(const ExpDw2Args& a, int k, int KS64, int nw, int gpw, unsigned grid, int lds_bytes, hipStream_t st) {
+#define XD2_GPW(KK, KS)                                                                    \
+  do {                                                                                     \
+    if (nw == 16) {                                                                        \
+      if (gpw == 1) launch_expdw2_t<KK, KS, 16, 1>(a, grid, lds_bytes, st);                \
+      else if (gpw == 2) launch_expdw2_t<KK, KS, 16, 2>(a, grid, lds_bytes, st);           \
+      else launch_expdw2_t<KK, KS, 16, 4>(a, grid, lds_bytes, st);                         \
+    } else {                                                                               \
+      if (gpw == 2) launch_expdw2_t<KK, KS, 8, 2>(a, grid, lds_bytes, st);                 \
+      else if (gpw == 4) launch_expdw2_t<KK, KS, 8, 4>(a, grid, lds_bytes, st);            \
+      else launch_expdw2_t<KK, KS, 8, 7>(a, grid, lds_bytes, st);                          \
+    }                                                                                      \
   } while (0)
 #define XD2_KS(KK)                  \
   do {                              \
@@ -75,7 +81,11 @@ int launch_expdw2(const ExpDw2Args& a, int k, int KS64, int gpw, unsigned grid, 
     else if (KS64 == 3) XD2_GPW(KK, 3); \
     else XD2_GPW(KK, 4);            \
   } while (0)
-  if ((k != 3 && k != 5) || KS64 < 2 || KS64 > 4 || (gpw != 2 && gpw != 4 && gpw != 7)) { set_error("expdw2: no kernel for k %d, %d K steps, %d groups per wave", k, KS64, gpw); return VBT_ERR_ARG; }
+  const bool gpw_ok = nw == 16 ? (gpw == 1 || gpw == 2 || gpw == 4) : (gpw == 2 || gpw == 4 || gpw == 7);
+  if ((k != 3 && k != 5) || KS64 < 2 || KS64 > 4 || (nw != 8 && nw != 16) || !gpw_ok) {
+    set_error("expdw2: no kernel for k %d, %d K steps, %d waves, %d groups per wave", k, KS64, nw, gpw);
+    return VBT_ERR_ARG;
+  }
   if (k == 3) XD2_KS(3);
   else XD2_KS(5);
 #undef XD2_KS
