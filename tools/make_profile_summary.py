@@ -17,7 +17,7 @@ import json
 import shutil
 import sys
 
-FAM = (("expdw_image", "fused_expand_dw"), ("sepconv_band", "fused_sepconv_band"), ("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"),
+FAM = (("expdw_image", "fused_expand_dw"), ("expdw2_kernel", "fused_expand_dw"), ("pw_d", "pw_conv_mfma_i8"), ("sepconv_band", "fused_sepconv_band"), ("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"),
        ("mbconv_image", "fused_mbconv"), ("dw_tile", "dw_conv"), ("dw_col", "dw_conv"), ("dw_kernel", "dw_conv"),
        ("pw_a", "pw_conv_mfma_i8"), ("pw_b", "pw_conv_mfma_i8"), ("pw_c", "pw_conv_mfma_i8"), ("stem_kernel", "stem_conv_mfma_i8"),
        ("add_kernel", "add_requant"), ("maxpool", "maxpool3x3s2"), ("resize_kernel", "resize_nn"), ("postprocess", "decode_nms"),
@@ -144,8 +144,10 @@ def summarize(src, pre, out_tag, title, plan, alg_mb_forward, alg_mb_frame, benc
                     f"{b.get('SQ_INSTS_VMEM_RD',0)/1e6:.2f} | {b.get('SQ_INSTS_MFMA',0)/1e6:.2f} | {100*mfma_busy:.1f} | {100*conf:.1f} | "
                     f"{100*a.get('SQ_WAIT_ANY',0)/wc:.1f} | {100*a.get('SQ_WAIT_INST_ANY',0)/wc:.1f} | {100*a.get('SQ_ACTIVE_INST_ANY',0)/wc:.1f} |\n")
         valu = sum(cb[k].get("SQ_INSTS_VALU", 0.0) for k in fams)
-        f.write(f"\nVALU issue floor of the forward: {valu/1e6:.0f} M wave-instructions x 2..4 cycles / 1024 SIMDs / 2.4 GHz = "
-                f"{valu*2/SIMDS/CLOCK*1e3:.3f}..{valu*4/SIMDS/CLOCK*1e3:.3f} ms (two or more waves per SIMD issue every 2 cycles, one wave every 4).\n\n")
+        f.write(f"\nVALU issue floor of the forward: {valu/1e6:.0f} M wave-instructions x 2.8..3.5 cycles / 1024 SIMDs / 2.4 GHz = "
+                f"{valu*2.8/SIMDS/CLOCK*1e3:.3f}..{valu*3.5/SIMDS/CLOCK*1e3:.3f} ms (issue cost per SIMD measured with tools/probes/valu_rate.hip for the "
+                f"VOP3 / VOP1 / packed forms the requantisation is made of: 3.5 cycles per wave-instruction with two waves per SIMD, 2.8 with four; "
+                f"plain VOP2 adds / multiplies 2.4 / 1.7; one wave alone 4.8-5.8).\n\n")
         # the two fractions BASELINE.json's north_star names
         dw_fams = [k for k in fams if k in ("dw_conv", "fused_expand_dw", "fused_sepconv_band")]
         pw = "pw_conv_mfma_i8"
