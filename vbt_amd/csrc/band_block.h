@@ -143,22 +143,24 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const float rcp_pw = frcp(PW);
   if (a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
-    if constexpr (C64) {
+    if (C64 || (C & 15) == 0) {
       // 16 channels of one pixel per lane-iteration (the stage used to walk dwords: four times the address arithmetic and four
       // times the dependent rounds of global loads - it was two thirds of a node kernel's time, tools/probes/bd_probe.hip); the
       // source loads of an iteration are all requested before its sums are formed
-      const int total = NPh * 4;
+      const int npp = C64 ? 4 : CS >> 4, nreal = C64 ? 4 : C >> 4;   // 16-byte pieces per LDS pixel row / of real channels
+      const float rcp_npp = frcp(npp);
+      const int total = NPh * npp;
       for (int i0 = tid; i0 < total; i0 += BD_LIT_NODE * nthreads) {
         uint4 us[BD_LIT_NODE][3];
-        int pofs[BD_LIT_NODE];   // LDS byte offset of the piece, -1: past the band; bit 30: outside the image (zero point)
+        int pofs[BD_LIT_NODE];   // LDS byte offset of the piece, -1: past the band; bit 30: outside the image or padding channels (zero point)
 #pragma unroll
         for (int k = 0; k < BD_LIT_NODE; k++) {
-          const int i = i0 + k * nthreads;
-          const int p = i >> 2, sg = i & 3;
-          const int hy = fdiv_small(min(p, NPh - 1), rcp_pw), hx = p - hy * PW;
+          const int i = i0 + k * nthreads, ic = min(i, total - 1);
+          const int p = C64 ? ic >> 2 : fdiv_small(ic, rcp_npp), sg = ic - p * npp;
+          const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
           const int iy = y0 + hy - 1, ix = hx - 1;
-          const bool in = i < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-          pofs[k] = i < total ? (p * 80 + 16 * sg) | (in ? 0 : (1 << 30)) : -1;
+          const bool in = i < total && sg < nreal && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          pofs[k] = i < total ? (p * CS + 16 * sg) | (in ? 0 : (1 << 30)) : -1;
 #pragma unroll
           for (int j = 0; j < 3; j++) {
             us[k][j] = make_uint4(0u, 0u, 0u, 0u);
