@@ -22,6 +22,7 @@
 constexpr int BD_WAVES = VBT_BD_WAVES, BD_THREADS = 64 * BD_WAVES;
 constexpr int BD_LIT = 3;           // lane-iterations of the load stage whose global loads are in flight together (plain input)
 constexpr int BD_LIT_NODE = 1;      // the same for a node's source loads (up to three 16-byte loads per iteration; registers: the head layers share this kernel)
+constexpr int BD_LIT_NODE_WIDE = 3; // maps of more than 64 channels: LDS leaves at most four waves per SIMD, so 128 registers are free to use
 constexpr int BD_WP_TAIL = 1024;   // bias (512 B) | multipliers (512 B) behind the projection weights in LDS
 
 // Developer build (tools/probes/bd_probe.hip): s_memtime stamps of wave 0 at the stage boundaries of every workgroup.
@@ -147,14 +148,15 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       // 16 channels of one pixel per lane-iteration (the stage used to walk dwords: four times the address arithmetic and four
       // times the dependent rounds of global loads - it was two thirds of a node kernel's time, tools/probes/bd_probe.hip); the
       // source loads of an iteration are all requested before its sums are formed
+      constexpr int LITN = C64 ? BD_LIT_NODE : BD_LIT_NODE_WIDE;
       const int npp = C64 ? 4 : CS >> 4, nreal = C64 ? 4 : C >> 4;   // 16-byte pieces per LDS pixel row / of real channels
       const float rcp_npp = frcp(npp);
       const int total = NPh * npp;
-      for (int i0 = tid; i0 < total; i0 += BD_LIT_NODE * nthreads) {
-        uint4 us[BD_LIT_NODE][3];
-        int pofs[BD_LIT_NODE];   // LDS byte offset of the piece, -1: past the band; bit 30: outside the image or padding channels (zero point)
+      for (int i0 = tid; i0 < total; i0 += LITN * nthreads) {
+        uint4 us[LITN][3];
+        int pofs[LITN];   // LDS byte offset of the piece, -1: past the band; bit 30: outside the image or padding channels (zero point)
 #pragma unroll
-        for (int k = 0; k < BD_LIT_NODE; k++) {
+        for (int k = 0; k < LITN; k++) {
           const int i = i0 + k * nthreads, ic = min(i, total - 1);
           const int p = C64 ? ic >> 2 : fdiv_small(ic, rcp_npp), sg = ic - p * npp;
           const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
           }
         }
 #pragma unroll
-        for (int k = 0; k < BD_LIT_NODE; k++) {
+        for (int k = 0; k < LITN; k++) {
           if (pofs[k] < 0) continue;
           uint4 v = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
           if (!(pofs[k] >> 30)) {
@@ -233,6 +235,30 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
           if (pofs[k] >= 0) *(uint4*)(T0 + pofs[k]) = v[k];
       }
     } else {
+    if ((C & 15) == 0) {
+      // 16-byte pieces, BD_LIT loads in flight (Lite2's 112-channel maps: the 8-byte walk below was nine dependent rounds of loads per band)
+      const int npp = CS >> 4, nreal = C >> 4;
+      const float rcp_npp = frcp(npp);
+      const uint4 z4 = make_uint4(a.zx4, a.zx4, a.zx4, a.zx4);
+      const int total = NPh * npp;
+      for (int i0 = tid; i0 < total; i0 += BD_LIT * nthreads) {
+        uint4 v[BD_LIT];
+        int pofs[BD_LIT];
+#pragma unroll
+        for (int k = 0; k < BD_LIT; k++) {
+          const int i = i0 + k * nthreads, ic = min(i, total - 1);
+          const int p = fdiv_small(ic, rcp_npp), sg = ic - p * npp;
+          const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
+          const int iy = y0 + hy - 1, ix = hx - 1;
+          pofs[k] = i < total ? p * CS + 16 * sg : -1;
+          v[k] = z4;
+          if (i < total && sg < nreal && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v[k] = *(const uint4*)(xb + (iy * a.W + ix) * C + 16 * sg);
+        }
+#pragma unroll
+        for (int k = 0; k < BD_LIT; k++)
+          if (pofs[k] >= 0) *(uint4*)(T0 + pofs[k]) = v[k];
+      }
+    } else {
     const int ngp = CS >> 3, ng = C >> 3;              // 8-byte granules per LDS row / of real channels
     const float rcp_ngp = frcp(ngp);
     const uint2 z2 = make_uint2(a.zx4, a.zx4);
@@ -243,6 +269,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       uint2 v = z2;
       if (sg < ng && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *(const uint2*)(xb + (iy * a.W + ix) * C + 8 * sg);
       *(uint2*)(T0 + p * CS + 8 * sg) = v;
+    }
     }
     }
   }
@@ -361,6 +388,10 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #define VBT_BD_HEAD_MAXPX 240
 #endif
 constexpr int BD_HEAD_WAVES = VBT_BD_HEAD_WAVES, BD_HEAD_MAXPX = VBT_BD_HEAD_MAXPX;
+// Maps of more than 64 channels (Lite1 / Lite2): 8 waves as well.  16 measured slower although a band's stages got shorter (Lite2 head layer
+// at 56x56, tools/probes/bd_probe.hip: 16 300 cycles per band against 21 000): the 60-register kernel no longer fits two 16-wave
+// workgroups on a CU, and one workgroup per CU loses more than the evener split of the 7 channel groups over 14 of 16 waves gains.
+constexpr int BD_HEAD_WAVES_WIDE = 8;
 #ifdef VBT_DEFINE_BAND_KERNELS   // the entry points are not templates: exactly one translation unit (k_band.hip) defines them
 __device__ __forceinline__ int band_problem(const MultiTiles& mt) {
   int pi = 0;
@@ -374,10 +405,10 @@ __global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const 
   const int pi = band_problem(mt);
   sepconv_band_body<BD_HEAD_WAVES, true>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
-__global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_wide_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+__global__ __launch_bounds__(64 * BD_HEAD_WAVES_WIDE) void sepconv_band_wide_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   const int pi = band_problem(mt);
-  sepconv_band_body<BD_HEAD_WAVES, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+  sepconv_band_body<BD_HEAD_WAVES_WIDE, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
 // One problem (a BiFPN node): the arguments travel in the kernel-argument segment, one dependent memory round trip
 // less at the head of a kernel that is a chain of round trips.

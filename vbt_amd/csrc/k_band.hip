@@ -26,7 +26,7 @@ int launch_band_one(const BandArgs& a, unsigned grid, int lds_bytes, hipStream_t
 int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, int C, unsigned grid, int lds_bytes, hipStream_t st) {
   band_attrs();
   if (C == 64) sepconv_band_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES, lds_bytes, st>>>(d_probs, mt);
-  else sepconv_band_wide_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES, lds_bytes, st>>>(d_probs, mt);
+  else sepconv_band_wide_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES_WIDE, lds_bytes, st>>>(d_probs, mt);
   return VBT_OK;
 }
 
