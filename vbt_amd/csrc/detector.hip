@@ -1904,12 +1904,12 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
 // ---- second form of the expand + depthwise kernel (expdw2_block.h): stride 1, Cin % 16 == 0 ----
 // LDS cycles of the depthwise operand reads (ds_read_b128: four groups of 16 lanes, one cycle per group when its 16-byte pieces
 // fall on distinct quarters of the 64 banks; equal addresses broadcast) summed over the positions of a band, for a row stride EYS
-static long xd2_read_cycles(int OHb, int XB, int EYS) {
+static long xd2_read_cycles(int PR, int XB, int EYS, int RM) {   // PR position rows, RM rows of the expanded image between them
   static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                  {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                  {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
                                  {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
-  const int NPOS = OHb * XB;
+  const int NPOS = PR * XB;
   long cycles = 0;
   for (int pg = 0; pg * 16 < NPOS; pg++)
     for (int k = 0; k < 4; k++) {
@@ -1917,7 +1917,7 @@ static long xd2_read_cycles(int OHb, int XB, int EYS) {
       int worst = 1;
       for (int j = 0; j < 16; j++) {
         const int lane = grp[k][j], r = lane & 15, g = lane >> 4, n = std::min(pg * 16 + r, NPOS - 1);
-        const int addr = (n / XB) * EYS + (n % XB) * 16 + (g >> 1) * EYS + 16 * (g & 1);
+        const int addr = (n / XB) * RM * EYS + (n % XB) * 16 + (g >> 1) * EYS + 16 * (g & 1);
         std::vector<int>& v = seen[(addr >> 4) & 15];
         if (std::find(v.begin(), v.end(), addr) == v.end()) v.push_back(addr);
         worst = std::max(worst, (int)v.size());
@@ -1927,25 +1927,28 @@ static long xd2_read_cycles(int OHb, int XB, int EYS) {
   return cycles;
 }
 struct ExpDw2Geom { bool ok; int nbands, brows, XB, EQS, EYS, e_bytes, PS, pe_off, pd_off, lds, gpw, gpw16; };
-static ExpDw2Geom expdw2_geom(int H, int W, int OH, int OW, int k, int pad_t, int KS64, int nbands) {
+static ExpDw2Geom expdw2_geom(int H, int W, int OH, int OW, int k, int stride, int pad_t, int KS64, int nbands) {
   ExpDw2Geom g{};
+  const int DY = stride, DX = 4 / stride;   // output pixels of a depthwise position: 1 x 4 (stride 1), 2 x 2 (stride 2)
   g.brows = (OH + nbands - 1) / nbands;
+  if (DY == 2) g.brows = (g.brows + 1) & ~1;   // whole row pairs per band
   g.nbands = (OH + g.brows - 1) / g.brows;
-  g.XB = (OW + 3) / 4;
-  const int KT2 = (k + 1) / 2, PW = OW - 1 + k;
+  g.XB = (OW + DX - 1) / DX;
+  const int KT2 = (stride * (DY - 1) + k + 1) / 2, PW = (OW - 1) * stride + k;
   g.EQS = (4 * PW + 15) & ~15;
   int in_rows = 0;
   for (int b = 0; b < g.nbands; b++) {
     const int oy0 = b * g.brows, oy1 = std::min(oy0 + g.brows, OH);
-    const int lo = std::max(oy0 - pad_t, 0), hi = std::min(oy0 - pad_t + (oy1 - oy0) - 1 + k, H);
+    const int lo = std::max(oy0 * stride - pad_t, 0), hi = std::min(oy0 * stride - pad_t + (oy1 - oy0 - 1) * stride + k, H);
     in_rows = std::max(in_rows, hi - lo);
   }
+  const int PR = (g.brows + DY - 1) / DY;   // position rows of the tallest band
   long best = -1;
   for (int pad = 0; pad < 256; pad += 16) {
-    const long cyc = xd2_read_cycles(g.brows, g.XB, 16 * g.EQS + pad);
+    const long cyc = xd2_read_cycles(PR, g.XB, 16 * g.EQS + pad, stride * DY);
     if (best < 0 || cyc < best) { best = cyc; g.EYS = 16 * g.EQS + pad; }
   }
-  const int PHe = g.brows - 1 + 2 * KT2;   // the last MFMA of a 5x5 (3x3) reads one row past the kernel: zero weights, but the row must exist
+  const int PHe = stride * DY * (PR - 1) + 2 * KT2;   // the last MFMA of a position may read a row past the kernel: zero weights, but the row must exist
   g.e_bytes = (PHe * g.EYS + 32 + 15) & ~15;
   int ps4 = g.brows * OW;
   while ((ps4 & 31) != 2) ps4++;
@@ -1959,13 +1962,14 @@ static ExpDw2Geom expdw2_geom(int H, int W, int OH, int OW, int k, int pad_t, in
   g.gpw16 = need16 <= 1 ? 1 : need16 <= 2 ? 2 : need16 <= 4 ? 4 : 0;
   if (g.gpw16 * KS64 > 8) g.gpw16 = 0;    // (the input operands a wave keeps: 4 registers each; beyond these the kernels spill)
   if (g.gpw * KS64 > 21) g.gpw = 0;
-  g.ok = g.gpw > 0 && g.lds <= 100 * 1024 && g.brows * g.XB <= 16 * XD2_NPG && g.e_bytes < 65536 && 16 * g.PS < 65535;   // (16-bit LDS offsets in the kernel)
+  if (stride == 2) g.gpw = 0;             // stride 2 exists on 16 waves only
+  g.ok = (g.gpw > 0 || g.gpw16 > 0) && g.lds <= 100 * 1024 && PR * g.XB <= 16 * XD2_NPG && g.e_bytes < 65536 && 16 * g.PS < 65535;   // (16-bit LDS offsets in the kernel)
   return g;
 }
-static ExpDw2Geom expdw2_choose(int H, int W, int OH, int OW, int k, int pad_t, int KS64) {
+static ExpDw2Geom expdw2_choose(int H, int W, int OH, int OW, int k, int stride, int pad_t, int KS64) {
   ExpDw2Geom g{};
   for (int nb = 1; nb <= OH; nb++) {
-    g = expdw2_geom(H, W, OH, OW, k, pad_t, KS64, nb);
+    g = expdw2_geom(H, W, OH, OW, k, stride, pad_t, KS64, nb);
     if (g.ok) return g;
   }
   g.ok = false;
@@ -1979,8 +1983,8 @@ static int make_expdw2(vbt_model* m, int e_op, int d_op, Step* s, const std::vec
   const ExpDwArgs& a1 = s->xd;
   s->xd2_ok = false;
   const int KS64 = (a1.Cin + 63) / 64;
-  if (!enabled || dop.stride != 1 || (dop.k != 3 && dop.k != 5) || a1.Cin % 8 != 0 || KS64 < 2 || KS64 > 4) return VBT_OK;
-  const ExpDw2Geom geo = expdw2_choose(a1.H, a1.W, a1.OH, a1.OW, dop.k, a1.pad_t, KS64);
+  if (!enabled || (dop.stride != 1 && dop.stride != 2) || (dop.k != 3 && dop.k != 5) || a1.Cin % 8 != 0 || KS64 < 2 || KS64 > 4) return VBT_OK;
+  const ExpDw2Geom geo = expdw2_choose(a1.H, a1.W, a1.OH, a1.OW, dop.k, dop.stride, a1.pad_t, KS64);
   if (!geo.ok) return VBT_OK;
   ExpDw2Args& a = s->xd2;
   memset(&a, 0, sizeof(a));
@@ -1990,7 +1994,7 @@ static int make_expdw2(vbt_model* m, int e_op, int d_op, Step* s, const std::vec
   a.XB = geo.XB; a.EQS = geo.EQS; a.EYS = geo.EYS; a.e_bytes = geo.e_bytes; a.PS = geo.PS; a.pe_off = geo.pe_off; a.pd_off = geo.pd_off;
   a.rqe = a1.rqe; a.zeb = a1.zeb; a.rqd = a1.rqd;
   const TensorRec& te = m->tensors[m->ops[e_op].output];
-  const int Ce = te.c, nch = a.nchunks, kk = dop.k, KT2 = (kk + 1) / 2;
+  const int Ce = te.c, nch = a.nchunks, kk = dop.k, S = dop.stride, KT2 = (S * (S - 1) + kk + 1) / 2;
   const int NE = KS64 * 256 + 32, ND = KT2 * 256 + 32;
   const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
   std::vector<v4i> ppe((size_t)nch * NE), ppd((size_t)nch * ND);
@@ -2004,11 +2008,13 @@ static int make_expdw2(vbt_model* m, int e_op, int d_op, Step* s, const std::vec
     for (int q = 0; q < 16; q++)
       for (int mi = 0; mi < KT2; mi++)
         for (int lane = 0; lane < 64; lane++) {
-          const int i = lane & 15, g = lane >> 4, dx = i >> 2, cc = i & 3, ch = 64 * c + 4 * q + cc, ty = 2 * mi + (g >> 1);
+          const int i = lane & 15, g = lane >> 4, qq = i >> 2, cc = i & 3, ch = 64 * c + 4 * q + cc;
+          const int dy = S == 2 ? qq >> 1 : 0, dx = S == 2 ? qq & 1 : qq;   // the output pixel of the position this operand row computes
+          const int ty = 2 * mi + (g >> 1) - S * dy;
           unsigned w4 = 0;
           for (int j = 0; j < 4; j++) {
-            const int tx = 4 * (g & 1) + j - dx;
-            if (ty < kk && tx >= 0 && tx < kk && ch < Ce) w4 |= (unsigned)(uint8_t)wd[(size_t)(ty * kk + tx) * Ce + ch] << (8 * j);
+            const int tx = 4 * (g & 1) + j - S * dx;
+            if (ty >= 0 && ty < kk && tx >= 0 && tx < kk && ch < Ce) w4 |= (unsigned)(uint8_t)wd[(size_t)(ty * kk + tx) * Ce + ch] << (8 * j);
           }
           tab[(q * KT2 + mi) * 64 + lane] = w4;
         }
@@ -2757,9 +2763,10 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       // VBT_XD_VARIANT (tests): that variant for every step that supports it, whatever the plan says
       static const int xd_force = getenv("VBT_XD_VARIANT") ? atoi(getenv("VBT_XD_VARIANT")) : -100;
       int variant = s.variant;
-      if (xd_force != -100 && (xd_force < 100 || (s.xd2_ok && (xd_force < 200 || s.xd2_gpw16 > 0)))) variant = std::min(xd_force, xd_force / 100 * 100 + s.xd.nchunks);
+      if (xd_force != -100 && (xd_force < 100 || (s.xd2_ok && (xd_force < 200 ? s.xd2_gpw > 0 : s.xd2_gpw16 > 0)))) variant = std::min(xd_force, xd_force / 100 * 100 + s.xd.nchunks);
       if (s.xd2_ok && (variant >= 100 || variant < 0)) {
         if (variant >= 200 && s.xd2_gpw16 == 0) { set_error("expand + depthwise: plan asks for the 16-wave form on a step that does not support it"); return VBT_ERR_ARG; }
+        if (variant >= 100 && variant < 200 && s.xd2_gpw == 0) { set_error("expand + depthwise: plan asks for the 8-wave form on a step that does not support it"); return VBT_ERR_ARG; }
         const int nw = (variant >= 200 || (variant < 0 && s.xd2_gpw16 > 0)) ? 16 : 8;
         ExpDw2Args a = s.xd2;
         a.x = TP(eop.inputs[0]);
@@ -2767,7 +2774,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         a.cpw = variant >= 100 ? variant % 100 : std::max(1, (a.nchunks * a.nbands * B + 1023) / 1024);   // default: about four workgroups per CU
         a.cpw = std::min(a.cpw, a.nchunks);
         const int ngroups = (a.nchunks + a.cpw - 1) / a.cpw;
-        const int rc = launch_expdw2(a, dop.k, (a.Cin + 63) / 64, nw, nw == 16 ? s.xd2_gpw16 : s.xd2_gpw, (unsigned)(B * ngroups * a.nbands), s.xd2_lds, st);
+        const int rc = launch_expdw2(a, dop.k, dop.stride, (a.Cin + 63) / 64, nw, nw == 16 ? s.xd2_gpw16 : s.xd2_gpw, (unsigned)(B * ngroups * a.nbands), s.xd2_lds, st);
         if (rc) return rc;
         break;
       }
@@ -2896,7 +2903,7 @@ static void autotune(vbt_model* m) {
           if (st.xd2_ok)
             for (int cpw : {1, 2, 3, 4, 6})
               if (cpw <= st.xd.nchunks) {
-                cand.push_back(100 + cpw);
+                if (st.xd2_gpw > 0) cand.push_back(100 + cpw);
                 if (st.xd2_gpw16 > 0) cand.push_back(200 + cpw);
               }
         }

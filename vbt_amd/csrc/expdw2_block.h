@@ -1,4 +1,4 @@
-// Low-resolution MBConv, first half (expand 1x1 + ReLU6 -> depthwise kxk, stride 1), second form of expdw_block.h.  Same split
+// Low-resolution MBConv, first half (expand 1x1 + ReLU6 -> depthwise kxk, stride 1 or 2), second form of expdw_block.h.  Same split
 // of the work - workgroup (image b, row band, channel group) produces `cpw` 64-channel chunks of the depthwise output, the
 // projection runs afterwards as a pointwise GEMM - and the same arithmetic (int32 accumulation, one float requantisation per
 // element), but organised around what the stage stamps of tools/probes/xd_probe.hip showed for the first form: its stages did not
@@ -22,7 +22,9 @@
 //     vector-memory instructions per wave and chunk - 8 waves x 22 x 16 address cycles = 2800 cycles of the CU's one address path,
 //     the fixed cost the stage stamps showed in every interval.
 //   * LDS: E 39 KB + D 26 KB at 20x20 (was 120 KB): two workgroups per CU, so one's expand overlaps the other's depthwise.
-// Stride-2 blocks and inputs whose channel count is not a multiple of 8 stay on expdw_block.h.
+//   * Stride 2: the operand covers 2 x 2 output pixels x 4 channels (rows 4 py .. 4 py + k + 1 of the expanded image, 8 columns from 4 px:
+//     3 MFMAs per 256 outputs for 3x3, 4 for 5x5 - the diagonal form takes 3 / 7), positions are (output row pair, output column pair).
+// Inputs whose channel count is not a multiple of 8 stay on expdw_block.h.
 #pragma once
 #include <type_traits>
 
@@ -40,7 +42,7 @@ struct ExpDw2Args {
   int pad_t, pad_l;
   int nchunks, cpw;  // 64-channel chunks in all / per workgroup
   int nbands, brows; // row bands per image / output rows per band
-  int XB;            // blocks of 4 output columns per row
+  int XB;            // position columns per row: blocks of 4 output columns (stride 1) / of 2 (stride 2)
   int EQS, EYS;      // E: bytes per (row, quad) = 4 * padded width rounded to 16; bytes per row = 16 * EQS + bank-spreading pad
   int e_bytes;       // LDS bytes of E (tallest band, + slack for the reads past the last row)
   int PS;            // D: bytes per quad plane (4 * pixels of the tallest band, rounded so that PS / 4 = 2 mod 32)
@@ -76,17 +78,18 @@ __device__ __forceinline__ void d_pair(F& d_units, FC full_c, int NPGo) {
   }
 }
 
-// KK: depthwise kernel size (stride 1); KS64: 64-channel K steps of the expand; NW: waves per workgroup; GPW: input pixel groups a wave
+// KK / S: depthwise kernel size / stride; KS64: 64-channel K steps of the expand; NW: waves per workgroup; GPW: input pixel groups a wave
 // owns (>= ceil(pixel groups / (NW / 2))).
 // NW = 8: a wave expands a pair of 16-channel tiles on up to 7 pixel groups and runs the depthwise of two channel quads - 180-240
 // registers, two waves per SIMD.  NW = 16: a tile pair on up to 4 pixel groups, one quad - the compiler has to stay within 128
 // registers, four waves per SIMD: the vector ALU issues a wave-instruction every 2.8 cycles instead of 3.5
 // (tools/probes/valu_rate.hip) and a wave's LDS / MFMA waits are covered by three others instead of one.
-template <int KK, int KS64, int NW, int GPW>
+template <int KK, int S, int KS64, int NW, int GPW>
 __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
+  constexpr int DY = S, DX = 4 / S;   // output pixels of a depthwise position: 1 x 4 (stride 1), 2 x 2 (stride 2)
   constexpr int XD2_THREADS = 64 * NW, HW2 = NW / 2, QW = 16 / NW;   // threads; waves per tile pair; channel quads per wave in the depthwise
   extern __shared__ __attribute__((aligned(16))) unsigned char xd2_smem[];
-  constexpr int KT2 = (KK + 1) / 2;   // depthwise MFMAs per unit: two kernel rows each
+  constexpr int KT2 = (S * (DY - 1) + KK + 1) / 2;   // depthwise MFMAs per unit: two rows of the expanded image each
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   XD2_STAMP(0);
@@ -97,10 +100,10 @@ __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
   const int band = fdiv_small(rem, frcp(ngroups));
   const int grp = rem - band * ngroups;
   const int oy0 = band * a.brows, oy1 = min(oy0 + a.brows, a.OH), OHb = oy1 - oy0;
-  const int iy_lo = max(oy0 - a.pad_t, 0), iy_hi = min(oy0 - a.pad_t + OHb - 1 + KK, a.H);
-  const int erow0 = iy_lo + a.pad_t - oy0;                       // E row of input row iy_lo
+  const int iy_lo = max(oy0 * S - a.pad_t, 0), iy_hi = min(oy0 * S - a.pad_t + (OHb - 1) * S + KK, a.H);
+  const int erow0 = iy_lo + a.pad_t - oy0 * S;                   // E row of input row iy_lo
   const int HW = (iy_hi - iy_lo) * a.W, OHW = OHb * a.OW;        // pixels of the band: input / output
-  const int NPOS = OHb * a.XB, NPGo = (NPOS + 15) >> 4;          // depthwise positions (row, 4-column block) and their groups of 16
+  const int NPOS = ((OHb + DY - 1) / DY) * a.XB, NPGo = (NPOS + 15) >> 4;   // depthwise positions (DY rows x DX columns of outputs) and their groups of 16
   unsigned char* E = xd2_smem;
   unsigned char* D = E + a.e_bytes;
   const int c_first = grp * a.cpw, c_last = min(c_first + a.cpw, a.nchunks);
@@ -169,9 +172,10 @@ __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
 #pragma unroll
     for (int pg = 0; pg < XD2_NPG; pg++) {
       const int n = pg * 16 + r, nc = min(n, NPOS - 1);
-      const int y = fdiv_small(nc, rcp_xb), xk = nc - y * a.XB;
-      const int ox = 4 * xk + g;
-      dofs[pg] = (unsigned)(y * a.EYS + xk * 16 + gofs) | ((n < NPOS && ox < a.OW) ? (unsigned)((y * a.OW + ox) * 4 + cq0 * a.PS) << 16 : 0xffff0000u);
+      const int y = fdiv_small(nc, rcp_xb), xk = nc - y * a.XB;   // position (row, column); its first input row / column: S DY y, S DX xk = 4 xk
+      const int oy = DY * y + (S == 2 ? g >> 1 : 0), ox = DX * xk + (S == 2 ? g & 1 : g);
+      dofs[pg] = (unsigned)(S * DY * y * a.EYS + xk * 16 + gofs) |
+                 ((n < NPOS && oy < OHb && ox < a.OW) ? (unsigned)((oy * a.OW + ox) * 4 + cq0 * a.PS) << 16 : 0xffff0000u);
     }
   }
   // ---- copy-out: D (quad-planar) -> the depthwise output tensor, 16 bytes per lane ----

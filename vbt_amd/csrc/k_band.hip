@@ -52,27 +52,31 @@ int launch_expdw(const ExpDwArgs& a, int k, int stride, int KS64, unsigned grid_
   return VBT_OK;
 }
 
-template <int KK, int KS64, int NW, int GPW>
+template <int KK, int S, int KS64, int NW, int GPW>
 static void launch_expdw2_t(const ExpDw2Args& a, unsigned grid, int lds_bytes, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw2_kernel<KK, KS64, NW, GPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw2_kernel<KK, S, KS64, NW, GPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  expdw2_kernel<KK, KS64, NW, GPW><<<dim3(grid), 64 * NW, lds_bytes, st>>>(a);
+  expdw2_kernel<KK, S, KS64, NW, GPW><<<dim3(grid), 64 * NW, lds_bytes, st>>>(a);
 }
 
-int launch_expdw2(const ExpDw2Args& a, int k, int KS64, int nw, int gpw, unsigned grid, int lds_bytes, hipStream_t st) {
+int launch_expdw2(const ExpDw2Args& a, int k, int stride, int KS64, int nw, int gpw, unsigned grid, int lds_bytes, hipStream_t st) {
 #define XD2_GPW(KK, KS)                                                                    \
   do {                                                                                     \
-    if (nw == 16) {                                                                        \
-      if (gpw == 1) launch_expdw2_t<KK, KS, 16, 1>(a, grid, lds_bytes, st);                \
-      else if (gpw == 2) launch_expdw2_t<KK, KS, 16, 2>(a, grid, lds_bytes, st);           \
-      else launch_expdw2_t<KK, KS, 16, 4>(a, grid, lds_bytes, st);                         \
+    if (stride == 2) {   /* 16 waves only */                                               \
+      if (gpw == 1) launch_expdw2_t<KK, 2, KS, 16, 1>(a, grid, lds_bytes, st);             \
+      else if (gpw == 2) launch_expdw2_t<KK, 2, KS, 16, 2>(a, grid, lds_bytes, st);        \
+      else launch_expdw2_t<KK, 2, KS, 16, 4>(a, grid, lds_bytes, st);                      \
+    } else if (nw == 16) {                                                                 \
+      if (gpw == 1) launch_expdw2_t<KK, 1, KS, 16, 1>(a, grid, lds_bytes, st);             \
+      else if (gpw == 2) launch_expdw2_t<KK, 1, KS, 16, 2>(a, grid, lds_bytes, st);        \
+      else launch_expdw2_t<KK, 1, KS, 16, 4>(a, grid, lds_bytes, st);                      \
     } else {                                                                               \
-      if (gpw == 2) launch_expdw2_t<KK, KS, 8, 2>(a, grid, lds_bytes, st);                 \
-      else if (gpw == 4) launch_expdw2_t<KK, KS, 8, 4>(a, grid, lds_bytes, st);            \
-      else launch_expdw2_t<KK, KS, 8, 7>(a, grid, lds_bytes, st);                          \
+      if (gpw == 2) launch_expdw2_t<KK, 1, KS, 8, 2>(a, grid, lds_bytes, st);              \
+      else if (gpw == 4) launch_expdw2_t<KK, 1, KS, 8, 4>(a, grid, lds_bytes, st);         \
+      else launch_expdw2_t<KK, 1, KS, 8, 7>(a, grid, lds_bytes, st);                       \
     }                                                                                      \
   } while (0)
 #define XD2_KS(KK)                  \
@@ -82,8 +86,8 @@ int launch_expdw2(const ExpDw2Args& a, int k, int KS64, int nw, int gpw, unsigne
     else XD2_GPW(KK, 4);            \
   } while (0)
   const bool gpw_ok = nw == 16 ? (gpw == 1 || gpw == 2 || gpw == 4) : (gpw == 2 || gpw == 4 || gpw == 7);
-  if ((k != 3 && k != 5) || KS64 < 2 || KS64 > 4 || (nw != 8 && nw != 16) || !gpw_ok) {
-    set_error("expdw2: no kernel for k %d, %d K steps, %d waves, %d groups per wave", k, KS64, nw, gpw);
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2) || (stride == 2 && nw != 16) || KS64 < 2 || KS64 > 4 || (nw != 8 && nw != 16) || !gpw_ok) {
+    set_error("expdw2: no kernel for k %d, stride %d, %d K steps, %d waves, %d groups per wave", k, stride, KS64, nw, gpw);
     return VBT_ERR_ARG;
   }
   if (k == 3) XD2_KS(3);

@@ -36,9 +36,9 @@ int launch_band_one(const BandArgs& a, unsigned grid, int lds_bytes, hipStream_t
 int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, int C, unsigned grid, int lds_bytes, hipStream_t st);   // C: channels of the maps (all problems alike)
 // whole-image expand + depthwise (expdw_block.h)
 int launch_expdw(const ExpDwArgs& a, int k, int stride, int KS64, unsigned grid, int lds_bytes, hipStream_t st);
-// the same on the second form of the kernel (expdw2_block.h): stride 1; nw = waves per workgroup (8 or 16), gpw = input pixel groups per
-// wave (8 waves: 2, 4 or 7; 16 waves: 1, 2 or 4)
-int launch_expdw2(const ExpDw2Args& a, int k, int KS64, int nw, int gpw, unsigned grid, int lds_bytes, hipStream_t st);
+// the same on the second form of the kernel (expdw2_block.h); nw = waves per workgroup (8 or 16; stride 2: 16), gpw = input pixel groups
+// per wave (8 waves: 2, 4 or 7; 16 waves: 1, 2 or 4)
+int launch_expdw2(const ExpDw2Args& a, int k, int stride, int KS64, int nw, int gpw, unsigned grid, int lds_bytes, hipStream_t st);
 // network entry: stem 3x3/2 + first SeparableConv (stem_block.h)
 int launch_stem_block(const StemBlockArgs& a, bool full_range, unsigned grid, hipStream_t st);
 
