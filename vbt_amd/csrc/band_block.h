@@ -366,6 +366,38 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
     int pg = wave >> 2;
     for (; pg + (nwaves / 4) < NPG; pg += 2 * (nwaves / 4)) p_units(std::integral_constant<int, 2>{}, pg);
     if (pg < NPG) p_units(std::integral_constant<int, 1>{}, pg);
+  } else if (!C64 && NT <= nwaves && KS <= 2 && (nwaves - NT * (nwaves / NT)) * 8 <= nwaves) {   // (maps of more than 64 channels; at most an eighth of the waves without a tile)
+    // any other width (Lite1 / Lite2 maps, the heads' 9- / 36-channel outputs): wave w owns output tile w % NT and, of the pixel groups,
+    // every (NW / NT)-th one, so its weights / bias / multipliers are loop invariants held in registers (the unit loop below re-read
+    // them from LDS and re-derived (pixel group, tile) per unit: 40 vector instructions and 6 LDS reads per unit against 22 and 2)
+    const int t = wave % NT, sub = wave / NT, nsub = nwaves / NT;
+    if (sub < nsub) {
+      const int c0 = 16 * t + 4 * g;
+      v4i wv[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) wv[ks] = ks < KS ? *(const v4i*)(WP + ((t * KS + ks) * 64 + lane) * 16) : (v4i){0, 0, 0, 0};
+      const int4 bb = *(const int4*)(WB + 4 * c0);
+      const float4 mm = *(const float4*)(WB + 512 + 4 * c0);
+      auto p_units = [&](auto u_c, int pg0) {
+        constexpr int U = decltype(u_c)::value;
+        v4i dv[U][2], acc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++)
+            if (ks < KS) dv[u][ks] = *(const v4i*)(D + ((pg0 + u * nsub) * 16 + r) * CS + 16 * g + 64 * ks);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[0], dv[u][0], v4i_from(bb), 0, 0, 0);
+          if (KS > 1) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[1], dv[u][1], acc[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) store_unit(pg0 + u * nsub, t, acc[u], mm);
+      };
+      int pg = sub;
+      for (; pg + nsub < NPG; pg += 2 * nsub) p_units(std::integral_constant<int, 2>{}, pg);
+      if (pg < NPG) p_units(std::integral_constant<int, 1>{}, pg);
+    }
   } else {
     for (int u = wave; u < NU; u += nwaves) {
       const int pg = fdiv_small(u, rcp_nt), t = u - pg * NT;
