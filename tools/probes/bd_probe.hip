@@ -63,8 +63,8 @@ int main() {
   run<16>("node 20x20", 20, 10, 64, 2, 64);    // a BiFPN node, two sources, two bands per image
   run<16>("node 20x20", 20, 10, 64, 3, 64);
   run<16>("node 10x10", 10, 10, 64, 2, 64);
-  run<8, false>("lite2 head 56x56", 56, 4, 112, 0, 128, 112);
-  run<8, false>("lite2 head 28x28", 28, 8, 112, 0, 128, 112);
+  run<16, false>("lite2 head 56x56", 56, 4, 112, 0, 128, 112);
+  run<16, false>("lite2 head 28x28", 28, 8, 112, 0, 128, 112);
   run<16, false>("lite2 node 28x28", 28, 14, 112, 2, 64, 112);
   return 0;
 }

@@ -121,7 +121,8 @@ __device__ __forceinline__ uint4 band_source16(const BandArgs& a, int j, long b,
 // in flight cannot co-reside; 8 waves on bands of <= 240 pixels interleave twice as many phases - +1.3 % end to end).
 // C64: the map has 64 channels (Lite0): row stride, channel groups and K-steps are compile-time constants (the generic
 // form costs the Lite0 pipeline 3 % end to end: 95.0 k vs 98.0 k frames/s).
-template <int NW, bool C64>
+// NODES: the input may be a BiFPN node's sum of sources; false (the head-layer kernels) compiles that path - and its registers - out.
+template <int NW, bool C64, bool NODES = true>
 __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, unsigned char* bd_smem) {
   constexpr int nwaves = NW, nthreads = 64 * NW;
   const long b = fdiv_small(local, frcp(a.nbands));
@@ -142,7 +143,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   if (tid < 4 * NT) *(uint4*)(WB + 16 * tid) = *(const uint4*)((const unsigned char*)a.bp + 16 * tid);
   else if (tid >= 32 && tid < 32 + 4 * NT) *(uint4*)(WB + 512 + 16 * (tid - 32)) = *(const uint4*)((const unsigned char*)a.mp + 16 * (tid - 32));
   const float rcp_pw = frcp(PW);
-  if (a.n_src > 0) {
+  if (NODES && a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
     if (C64 || (C & 15) == 0) {
       // 16 channels of one pixel per lane-iteration (the stage used to walk dwords: four times the address arithmetic and four
@@ -420,10 +421,11 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #define VBT_BD_HEAD_MAXPX 240
 #endif
 constexpr int BD_HEAD_WAVES = VBT_BD_HEAD_WAVES, BD_HEAD_MAXPX = VBT_BD_HEAD_MAXPX;
-// Maps of more than 64 channels (Lite1 / Lite2): 8 waves as well.  16 measured slower although a band's stages got shorter (Lite2 head layer
-// at 56x56, tools/probes/bd_probe.hip: 16 300 cycles per band against 21 000): the 60-register kernel no longer fits two 16-wave
-// workgroups on a CU, and one workgroup per CU loses more than the evener split of the 7 channel groups over 14 of 16 waves gains.
-constexpr int BD_HEAD_WAVES_WIDE = 8;
+// Maps of more than 64 channels (Lite1 / Lite2): 16 waves, held to 64 registers so that two workgroups still share a CU.  With 6 or 7
+// channel groups only NCG * (NW / NCG) waves work in the depthwise stage - 7 of 8, each with every pixel group of the band, against 14 of
+// 16 with half of them (tools/probes/bd_probe.hip, Lite2 head layer at 56x56: 24 000 cycles per band on 8 waves, 16 300 on 16; with
+// one 16-wave workgroup per CU - what an 84-register build gets - the launch was slower all the same).
+constexpr int BD_HEAD_WAVES_WIDE = 16;
 #ifdef VBT_DEFINE_BAND_KERNELS   // the entry points are not templates: exactly one translation unit (k_band.hip) defines them
 __device__ __forceinline__ int band_problem(const MultiTiles& mt) {
   int pi = 0;
@@ -435,12 +437,12 @@ __device__ __forceinline__ int band_problem(const MultiTiles& mt) {
 __global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   const int pi = band_problem(mt);
-  sepconv_band_body<BD_HEAD_WAVES, true>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+  sepconv_band_body<BD_HEAD_WAVES, true, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
-__global__ __launch_bounds__(64 * BD_HEAD_WAVES_WIDE) void sepconv_band_wide_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+__global__ __launch_bounds__(64 * BD_HEAD_WAVES_WIDE, 2) void sepconv_band_wide_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   const int pi = band_problem(mt);
-  sepconv_band_body<BD_HEAD_WAVES_WIDE, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+  sepconv_band_body<BD_HEAD_WAVES_WIDE, false, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
 // One problem (a BiFPN node): the arguments travel in the kernel-argument segment, one dependent memory round trip
 // less at the head of a kernel that is a chain of round trips.

@@ -1593,7 +1593,8 @@ static int batch_heads(vbt_model* m) {
       const Step& fs = ta->steps[0];
       each.steps.push_back(fs);
       for (int t : ta->hidden) { each.hidden.push_back(t); multi.hidden.push_back(t); bandm.hidden.push_back(t); }
-      if (const Alt* ba = band_alt(src)) {
+      const Alt* ba = band_alt(src);
+      if (ba && ba->steps[0].bd_args.n_src == 0) {   // (the multi-problem band kernels are built without the node-sum path)
         Step b1 = ba->steps[0];
         {   // the head grid runs 8-wave workgroups on shorter bands (band_block.h)
           BandArgs& ha = b1.bd_args;
