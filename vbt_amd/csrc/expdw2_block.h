@@ -21,7 +21,8 @@
 //     16-byte loads per thread issued a stage ahead, and handed to the waves through LDS.  Per-wave loads of the same data cost 22
 //     vector-memory instructions per wave and chunk - 8 waves x 22 x 16 address cycles = 2800 cycles of the CU's one address path,
 //     the fixed cost the stage stamps showed in every interval.
-//   * LDS: E 39 KB + D 26 KB at 20x20 (was 120 KB): two workgroups per CU, so one's expand overlaps the other's depthwise.
+//   * LDS: E 39 KB + D 26 KB + parameters 21-25 KB at 20x20 (the first form: 120 KB).  One workgroup per CU either way; the 16-wave shape
+//     (below) puts four waves on every SIMD, so that one wave's LDS / MFMA waits are covered by three others.
 //   * Stride 2: the operand covers 2 x 2 output pixels x 4 channels (rows 4 py .. 4 py + k + 1 of the expanded image, 8 columns from 4 px:
 //     3 MFMAs per 256 outputs for 3x3, 4 for 5x5 - the diagonal form takes 3 / 7), positions are (output row pair, output column pair).
 // Inputs whose channel count is not a multiple of 8 stay on expdw_block.h.
@@ -51,9 +52,10 @@ struct ExpDw2Args {
   // per chunk, 16-byte pieces, copied to LDS as they are:
   const v4i* pe;     // expand: weights [ks][t][lane] x 16 B (row i of tile t = channel 64 c + 16 t + i, k = 64 ks + 16 g + j) | bias (input zero
                      // point folded) x 64 | multipliers x 64                                          = KS64 * 256 + 32 pieces
-  const v4i* pd;     // depthwise: [quad][mi][lane] dwords, byte j = w[2 mi + (g >> 1)][4 (g & 1) + j - dx][64 c + 4 quad + cc] for A row
-                     // (lane & 15) = 4 dx + cc (0 outside the kernel; the MFMA operand - dword j = that byte at byte position cc - is rebuilt
-                     // in registers) | bias (expanded zero point folded) x 64 | multipliers x 64       = KT2 * 256 + 32 pieces
+  const v4i* pd;     // depthwise: [quad][mi][lane] dwords, byte j = w[2 mi + (g >> 1) - S dy][4 (g & 1) + j - S dx][64 c + 4 quad + cc] for A row
+                     // (lane & 15) = 4 q + cc with q = dx (stride 1: dy = 0) or 2 dy + dx (stride 2); 0 outside the kernel; the MFMA operand
+                     // (dword j = that byte at byte position cc) is rebuilt in registers | bias (expanded zero point folded) x 64 |
+                     // multipliers x 64                                                                = KT2 * 256 + 32 pieces
   Rq rqe;
   unsigned zeb;      // zero point of the expanded tensor x4
   Rq rqd;
