@@ -173,6 +173,8 @@ __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
     const float rcp_xb = frcp(a.XB);
 #pragma unroll
     for (int pg = 0; pg < XD2_NPG; pg++) {
+      dofs[pg] = 0xffff0000u;
+      if (pg >= NPGo) continue;   // (uniform: a 10x10 map has two position groups, not eight)
       const int n = pg * 16 + r, nc = min(n, NPOS - 1);
       const int y = fdiv_small(nc, rcp_xb), xk = nc - y * a.XB;   // position (row, column); its first input row / column: S DY y, S DX xk = 4 xk
       const int oy = DY * y + (S == 2 ? g >> 1 : 0), ox = DX * xk + (S == 2 ? g & 1 : g);
