@@ -295,8 +295,8 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   // requested together and their MFMA chains interleave (one unit at a time, every MFMA waited for the one before it and every
   // unit for its own LDS round trip) ----
   if (sub < nsub) {
-    auto d_units = [&](auto u_c, int pg0) {
-      constexpr int U = decltype(u_c)::value;
+    auto d_units = [&](auto full_c, auto u_c, int pg0) {
+      constexpr int U = decltype(u_c)::value, FULL = decltype(full_c)::value;
       const unsigned char* pb[U];
       int slot[U];
 #pragma unroll
@@ -318,11 +318,15 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #pragma unroll
         for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wdv[m], bv[u][m], acc[u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < U; u++) *(unsigned*)(D + slot[u] * CS + 16 * cg + 4 * g) = rq_pack_b(acc[u], mu, a.rqd);
+      for (int u = 0; u < U; u++) *(unsigned*)(D + slot[u] * CS + 16 * cg + 4 * g) = rq_pack_b<FULL>(acc[u], mu, a.rqd);
     };
-    int pg = sub;
-    for (; pg + nsub < NPG; pg += 2 * nsub) d_units(std::integral_constant<int, 2>{}, pg);
-    if (pg < NPG) d_units(std::integral_constant<int, 1>{}, pg);
+    // the requantisation flavour (saturating / explicitly clamped) is uniform: picked once per stage, not once per unit
+    auto d_walk = [&](auto full_c) {
+      int pg = sub;
+      for (; pg + nsub < NPG; pg += 2 * nsub) d_units(full_c, std::integral_constant<int, 2>{}, pg);
+      if (pg < NPG) d_units(full_c, std::integral_constant<int, 1>{}, pg);
+    };
+    if (a.rqd.full) d_walk(std::integral_constant<int, 1>{}); else d_walk(std::integral_constant<int, 0>{});
   }
   __syncthreads();
   BD_STAMP(2);
@@ -350,8 +354,8 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
     const float4 mm = *(const float4*)(WB + 512 + 4 * c0);
     // two units in flight, the output address one 64-bit multiply-add per unit from a base formed once
     int8_t* ob = a.out + ((b * a.H + y0) * (long)a.W) * a.Cout + c0;   // the band's pixels are contiguous: (y0 + py) * W + px = y0 * W + slot
-    auto p_units = [&](auto u_c, int pg0) {
-      constexpr int U = decltype(u_c)::value;
+    auto p_units = [&](auto full_c, auto u_c, int pg0) {
+      constexpr int U = decltype(u_c)::value, FULL = decltype(full_c)::value;
       v4i dv[U], acc[U];
 #pragma unroll
       for (int u = 0; u < U; u++) dv[u] = *(const v4i*)(D + ((pg0 + u * (nwaves / 4)) * 16 + r) * CS + 16 * g);
@@ -360,13 +364,16 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int slot = (pg0 + u * (nwaves / 4)) * 16 + r;
-        const unsigned d = rq_pack_b(acc[u], mm, a.rqp);
+        const unsigned d = rq_pack_b<FULL>(acc[u], mm, a.rqp);
         if (slot < NPo) *(unsigned*)(ob + (long)slot * a.Cout) = d;
       }
     };
-    int pg = wave >> 2;
-    for (; pg + (nwaves / 4) < NPG; pg += 2 * (nwaves / 4)) p_units(std::integral_constant<int, 2>{}, pg);
-    if (pg < NPG) p_units(std::integral_constant<int, 1>{}, pg);
+    auto p_walk = [&](auto full_c) {
+      int pg = wave >> 2;
+      for (; pg + (nwaves / 4) < NPG; pg += 2 * (nwaves / 4)) p_units(full_c, std::integral_constant<int, 2>{}, pg);
+      if (pg < NPG) p_units(full_c, std::integral_constant<int, 1>{}, pg);
+    };
+    if (a.rqp.full) p_walk(std::integral_constant<int, 1>{}); else p_walk(std::integral_constant<int, 0>{});
   } else if (!C64 && NT <= nwaves && KS <= 2 && (nwaves - NT * (nwaves / NT)) * 8 <= nwaves) {   // (maps of more than 64 channels; at most an eighth of the waves without a tile)
     // any other width (Lite1 / Lite2 maps, the heads' 9- / 36-channel outputs): wave w owns output tile w % NT and, of the pixel groups,
     // every (NW / NT)-th one, so its weights / bias / multipliers are loop invariants held in registers (the unit loop below re-read
