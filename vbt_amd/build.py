@@ -32,7 +32,7 @@ def _headers():
 
 # Kernel headers whose change cannot affect a translation unit's code (launchers.h shows every argument struct to every unit, but
 # a unit only instantiates the kernels of its own headers).  Anything not listed here is a dependency of every unit.
-KERNEL_HEADERS = {"band_block.h", "expdw_block.h", "expdw2_block.h", "stem_block.h", "image_block.h", "fused_block.h"}
+KERNEL_HEADERS = {"op_kernels.h", "band_block.h", "expdw_block.h", "expdw2_block.h", "stem_block.h", "image_block.h", "fused_block.h"}
 UNIT_KERNEL_HEADERS = {
     "k_band.hip": {"band_block.h", "expdw_block.h", "expdw2_block.h", "stem_block.h", "fused_block.h"},
     "k_image.hip": {"image_block.h", "fused_block.h"},
