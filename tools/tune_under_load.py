@@ -78,10 +78,11 @@ for ln, text in enumerate(lines, 1):
                 opts.add(f"{a2} 1 -1"); opts.add(f"{a2} 1 1")
     elif ns == 1 and var[0] == -1 and alt >= 2:
         opts.add(f"{alt - 1} 1 1")
-    elif ns == 2 and var[0] in (1, 2, 3, 4, 6):                   # expand + depthwise: chunks per workgroup
-        for c in (1, 2, 3, 4, 6):
-            opts.add(f"{alt} 2 {c} {var[1]}")
-        for v in (-1, 2):                                        # the projection behind it: K-streaming / split-K variant
+    elif ns == 2 and var[0] % 100 in (1, 2, 3, 4, 6):             # expand + depthwise: chunks per workgroup x kernel form
+        for form in (0, 100, 200):                               # first form / second form on 8 waves / on 16 waves
+            for c in (1, 2, 3, 4, 6):
+                opts.add(f"{alt} 2 {form + c} {var[1]}")
+        for v in (-1, 2, 3, 4):                                  # the projection behind it: K-streaming / split-K / weights through LDS (64 / 128 pixels)
             opts.add(f"{alt} 2 {var[0]} {v}")
     opts.discard(text)
     if opts:
