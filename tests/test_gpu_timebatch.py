@@ -41,6 +41,10 @@ def test_run_schedule_properties():
         assert longest <= -(-slots * max(lengths) // sum(lengths)) + 1        # the sequential tracker walk of a step stays short
     capped = shard.run_schedule([100, 2], 64, max_run=8)
     assert max(nf for st in capped for _, _, nf, _ in st) == 8 and sum(nf for st in capped for c, _, nf, _ in st if c == 0) == 100
+    for bad in (dict(n_slots=0), dict(n_slots=4, max_run=0), dict(n_slots=4, max_run=-3)):   # used to loop for ever
+        with pytest.raises(ValueError):
+            shard.run_schedule([10, 3], **bad)
+    assert shard.run_schedule([], 8) == [] and shard.run_schedule([0, 0], 8) == []
 
 
 def _rows_equal(a, b):
@@ -141,6 +145,43 @@ def test_frame_step_and_empty_frames(model_path):
     pipe.finish()
     assert _rows_equal(pipe.rows(0), want) and len(want["id"]) > 10
     assert pipe.tracker.status(0)["frame_count"] == ref.tracker.status(0)["frame_count"] <= T // stride
+
+
+@pytest.mark.gpu
+def test_step_runs_validates_per_run_sources(model_path):
+    """Per-run source lists: raw pointers base + f * frame_bytes go to the gather kernel, so a short, strided,
+    wrongly shaped or wrongly typed source must be refused on the host; a source resolution whose frame size is not a multiple
+    of 16 bytes (7 x 5 x 3 = 105) takes the copy path and gives the rows of the assembled-batch form."""
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    bg = synth.background(4)
+    fd = torch.from_numpy(np.stack([synth.render(bg, t) for t in range(12)])).cuda()
+    pipe = Pipeline(model_path, 8, max_frames=32, fps=30.0, rows_per_frame=25, tracker_clips=2)
+    runs = [(0, 0, 4, 1), (1, 4, 4, 1)]
+    for bad in ([fd[:3], fd[4:8]],                                     # too few frames for the run
+                [fd[:8:2], fd[4:8]],                                   # strided
+                [fd[:4, :, :160], fd[4:8]],                            # another shape (and not contiguous)
+                [fd[:4].to(torch.int8), fd[4:8]],                      # another dtype
+                [fd[:4], fd[4:8].cpu()],                               # mixed devices
+                [fd[:4]]):                                             # one source per run
+        with pytest.raises(ValueError):
+            pipe.step_runs(bad, runs)
+    with pytest.raises(ValueError):
+        pipe.step_runs([fd[:4], fd[4:7]], [(0, 0, 4, 1), (1, 5, 3, 1)])   # hole at slot 4
+    pipe.step_runs([fd[:4], fd[4:8]], runs)                             # the valid call still runs after the refusals
+    pipe.finish()
+    assert len(pipe.rows(0)["id"]) > 0
+    small = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (8, 7, 5, 3), dtype=np.uint8)).cuda()
+    a = Pipeline(model_path, 8, max_frames=32, fps=30.0, rows_per_frame=25, tracker_clips=2)
+    a.step_runs([small[:4], small[4:]], runs, src_hw=(7, 5))
+    a.finish()
+    b = Pipeline(model_path, 8, max_frames=32, fps=30.0, rows_per_frame=25, tracker_clips=2)
+    b.step_runs(small, runs, src_hw=(7, 5))
+    b.finish()
+    assert all(_rows_equal(a.rows(c), b.rows(c)) for c in range(2))
+    da, db = a.detections(), b.detections()
+    assert all(np.array_equal(x, y) for x, y in zip(da, db))
 
 
 @pytest.mark.gpu

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvbt_hip.so")
+LIB_PATH = os.environ.get("VBT_LIB_PATH") or os.path.join(_HERE, "libvbt_hip.so")   # (VBT_LIB_PATH: developer builds with in-kernel stamps, tools/*_prof.py)
 _lib = None
 
 c_void_p, c_int, c_char_p, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_double

@@ -1952,7 +1952,14 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       for (int q = 127; q >= -128; q--)
         if (m->post_tables_host[q + 128] >= m->hdr.nms_score_threshold) qmin = q; else break;
       p.qmin = qmin;
-      postprocess_kernel<<<dim3((unsigned)B), 256, 0, st>>>(p, boxes, scores, classes, counts);
+      const int lds = post_lds_bytes(p.A);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&postprocess_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+      }
+      if (lds > 160 * 1024 || p.A > 65535) { set_error("decode + NMS: %d anchors do not fit the kernel (LDS %d bytes, 16-bit anchor index)", p.A, lds); return VBT_ERR_CAPACITY; }
+      postprocess_kernel<<<dim3((unsigned)B), POST_THREADS, lds, st>>>(p, boxes, scores, classes, counts);
       break;
     }
   }
@@ -2507,6 +2514,15 @@ int vbt_resize_frames(const uint8_t* src, int B, int H, int W, int src_on_device
   if (e != hipSuccess) { set_error("vbt_resize_frames failed: %s", hipGetErrorString(e)); return VBT_ERR_HIP; }
   return VBT_OK;
 }
+
+#ifdef VBT_POST_PROF
+int vbt_post_prof_read(unsigned long long* out16, int reset) {
+  if (reset) { unsigned long long z[16] = {0}; VBT_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vbt::g_post_prof), z, sizeof(z))); return VBT_OK; }
+  VBT_HIP_CHECK(hipDeviceSynchronize());
+  VBT_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(vbt::g_post_prof), 16 * sizeof(unsigned long long)));
+  return VBT_OK;
+}
+#endif
 
 int vbt_model_kernel_stats(const vbt_model* m, int B, vbt_kernel_stat* out, int cap, int* n) {
   if (!m || !out || !n || cap < F_COUNT) { set_error("bad argument"); return VBT_ERR_ARG; }

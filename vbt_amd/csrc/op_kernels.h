@@ -647,169 +647,402 @@ struct PostArgs {
   float iou_thr;
 };
 constexpr int POST_CAP = 2048;
+// Phase timers (developer builds only: VBT_EXTRA_CXXFLAGS=-DVBT_POST_PROF): s_memtime deltas of workgroup 0, thread 0, summed per phase;
+// read with vbt_post_prof_read (tools/post_prof.py).  The product build holds no stamp.
+#ifdef VBT_POST_PROF
+__device__ unsigned long long g_post_prof[16];
+#define POST_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_post_prof[i], t_ - t_last); t_last = t_; } } while (0)
+#else
+#define POST_STAMP(i) do { } while (0)
+#endif
 
-__device__ __forceinline__ float iou_box(float4 a, float4 b) {  // (ymin, xmin, ymax, xmax)
-  float area_a = (a.z - a.x) * (a.w - a.y);
-  float area_b = (b.z - b.x) * (b.w - b.y);
-  if (area_a <= 0.0f || area_b <= 0.0f) return 0.0f;
-  float iy0 = fmaxf(a.x, b.x), ix0 = fmaxf(a.y, b.y);
-  float iy1 = fminf(a.z, b.z), ix1 = fminf(a.w, b.w);
-  float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
-  return inter / (area_a + area_b - inter);
+// LDS carve-up (dynamic, every offset a multiple of 16): class bytes of the frame in anchor order | 32 KB: the 32 interleaved
+// histograms of pass 1, afterwards candidate keys, their sorted copy and the decoded boxes / scores | small tables.
+constexpr int POST_THREADS = 1024;  // one workgroup per frame: sixteen waves shorten every parallel phase of a latency-bound kernel
+constexpr int POST_FAST = 1024;     // rounds of at most this many candidates: counting sort + all boxes decoded at once, one per thread
+constexpr int POST_LDS_FIXED = 32768 + 1024 + 1024 + 2048 + 2048 + 256 + 32 * 16 + 128 + 128;   // (+ scalars, + areas of the selected boxes)
+static_assert(POST_CAP * 4 + POST_FAST * 4 + POST_FAST * 16 + POST_FAST * 4 <= 32768, "keys | sorted keys | boxes | scores share the histogram's 32 KB");
+__host__ __device__ inline int post_lds_bytes(int A) { return ((A + 15) & ~15) + POST_LDS_FIXED; }
+
+// inclusive prefix sum over the 64 lanes of a wavefront on the DPP path (row shifts inside rows of 16 lanes, then the row
+// broadcasts of GFX9): six dependent VALU instructions instead of six LDS-crossbar shuffles
+__device__ __forceinline__ int wave_incl_scan_i(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+// first lane whose flag is set (64: none), and a value of that lane (wave-uniform results, no shuffles)
+__device__ __forceinline__ int wave_first_lane(bool flag) {
+  const unsigned long long m = __ballot(flag);
+  return m ? __ffsll((long long)m) - 1 : 64;
 }
 
-__global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __restrict__ boxes, float* __restrict__ scores,
-                                                          float* __restrict__ classes, int* __restrict__ counts) {
-  __shared__ int hist[256];
-  __shared__ unsigned keys[POST_CAP];
-  __shared__ float s_score[256];            // dequantised LOGISTIC output per class byte
-  __shared__ double s_dq[256], s_ex[256];   // (double)box / y_scale and exp((double)box / h_scale) per box byte
-  __shared__ float4 selbox[VBT_MAX_DETECTIONS + 7];
-  __shared__ int s_n, s_qlo, s_qhi, s_i0, s_i1, s_nsel, s_done;
-  const int tid = threadIdx.x;
+// One workgroup per frame.  Latency is what matters here (one frame = one workgroup, nothing to overlap it with inside a
+// forward), so every phase is laid out for few dependent round trips and short dependent chains:
+//   1. the frame's class bytes (A of them, five level tensors) are copied into LDS with ALL loads of a thread in flight at once;
+//   2. histogram of the class bytes in 32 interleaved copies (lane l adds to copy l & 31: every lane of a half-wave owns a bank,
+//      so the bulk of the anchors, which shares a handful of bins, does not serialise), folded into a histogram of RANK bytes
+//      (equal scores share a rank);
+//   3. wavefront 0 picks the next range of ranks, from the top: a prefix scan over the 256 bins (bins are added while fewer than
+//      256 candidates are held and the next one still fits POST_CAP; one oversized bin is walked in slices of anchor indices);
+//   4. candidates of that range: counted per thread, block-wide exclusive scan, written as keys (127 - rank) << 16 | anchor;
+//      ascending key = (score desc, anchor asc), the reference's stable sort; <= POST_FAST keys are sorted by counting (no
+//      barriers inside), more by a bitonic network;
+//   5. <= POST_FAST candidates are decoded by all threads at once (one round trip for box bytes + anchors) into LDS;
+//   6. greedy suppression by wavefront 0; next round only if fewer than max_det boxes survived.
+__global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, float* __restrict__ boxes, float* __restrict__ scores,
+                                                                   float* __restrict__ classes, int* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char post_smem[];
+  constexpr int NT = POST_THREADS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long b = blockIdx.x;
-  const int8_t* cls[5];
-  const int8_t* box[5];
-#pragma unroll
-  for (int l = 0; l < 5; l++) {
-    int nl = p.base[l + 1] - p.base[l];
-    cls[l] = p.cls[l] + b * nl;
-    box[l] = p.box[l] + b * (long)nl * 4;
+#ifdef VBT_POST_PROF
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
+  const int A = p.A;
+  // fixed-size regions first (compile-time LDS addresses), the class bytes - the one region whose size depends on the model - last
+  int* hist32 = (int*)post_smem;                                   // [256][32] during pass 1; afterwards:
+  unsigned* keys = (unsigned*)hist32;                              // [POST_CAP]
+  unsigned* skeys = keys + POST_CAP;                               // [POST_FAST]
+  float4* lbox = (float4*)(skeys + POST_FAST);                     // [POST_FAST]
+  float* lsc = (float*)(lbox + POST_FAST);                         // [POST_FAST]
+  int* rhist = (int*)(post_smem + 32768);                          // [256] candidates per rank byte
+  float* s_score = (float*)(rhist + 256);                          // dequantised LOGISTIC output per rank byte
+  double* s_dq = (double*)(s_score + 256);                         // (double)box / y_scale per box byte
+  double* s_ex = s_dq + 256;                                       // exp((double)box / h_scale) per box byte
+  signed char* s_rank = (signed char*)(s_ex + 256);                // rank byte per class byte
+  float4* selbox = (float4*)(s_rank + 256);                        // [32] boxes selected so far
+  int* sv = (int*)(selbox + 32);                                   // scalars + per-wave totals
+  unsigned char* cb = post_smem + POST_LDS_FIXED;                  // [A16] class bytes in anchor order
+  int& s_n = sv[0]; int& s_qlo = sv[1]; int& s_qhi = sv[2]; int& s_i0 = sv[3]; int& s_i1 = sv[4]; int& s_nsel = sv[5]; int& s_done = sv[6];
+  int& s_blo = sv[7]; int& s_bhi = sv[8];
+  int* s_wtot = sv + 12;                                           // [16]
+  // ---- 1. class bytes -> registers (+ LDS).  The frame's A class bytes, five level tensors, are taken as ONE array in anchor order;
+  // thread t owns the dwords i = t + 1024 k (anchors 4 i .. 4 i + 3).  A dword that lies inside one level at a dword-aligned
+  // address is one load (all PS loads of a thread are in flight together); the few that straddle two levels or sit in a
+  // level whose frame offset is odd (9 H W bytes per frame) are patched byte by byte afterwards.
+  constexpr int PS = 5;                        // dword slots per thread (x 1024 threads x 4 anchors: Lite0); beyond that: loops over LDS
+  const int n4 = (A + 3) >> 2;                 // (bytes past A inside the last dword are excluded by their anchor index)
+  const int b1 = p.base[1], b2 = p.base[2], b3 = p.base[3], b4 = p.base[4];
+  auto level_of = [&](int a) -> int { return (a >= b1) + (a >= b2) + (a >= b3) + (a >= b4); };
+  // Anchor a's class byte sits at pc0 + a + (sum of the steps of the level boundaries at or below a): every level pointer is
+  // biased by its first anchor, and the choice of the level is four conditional 64-bit adds (a select chain over five pointers
+  // is turned into a table in scratch memory by the compiler: a dependent load per address).
+  const unsigned char *pc0, *pb0;
+  long ce1, ce2, ce3, ce4, be1, be2, be3, be4;
+  {
+    auto cbias = [&](int l) { return (long)p.cls[l] + b * (long)(p.base[l + 1] - p.base[l]) - p.base[l]; };
+    auto bbias = [&](int l) { return (long)p.box[l] + (b * (long)(p.base[l + 1] - p.base[l]) - p.base[l]) * 4; };
+    pc0 = (const unsigned char*)cbias(0); pb0 = (const unsigned char*)bbias(0);
+    ce1 = cbias(1) - cbias(0); ce2 = cbias(2) - cbias(1); ce3 = cbias(3) - cbias(2); ce4 = cbias(4) - cbias(3);
+    be1 = bbias(1) - bbias(0); be2 = bbias(2) - bbias(1); be3 = bbias(3) - bbias(2); be4 = bbias(4) - bbias(3);
   }
-  hist[tid] = 0;
-  __shared__ signed char s_rank[256];
-  s_score[tid] = ((const float*)p.tables)[tid];
-  s_dq[tid] = ((const double*)(p.tables + 1024))[tid];
-  s_ex[tid] = ((const double*)(p.tables + 3072))[tid];
-  s_rank[tid] = ((const signed char*)(p.tables + 5120))[tid];
+  auto cls_ptr = [&](int a) -> const unsigned char* {      // address of anchor a's class byte
+    long o = a;
+    o += a >= b1 ? ce1 : 0l; o += a >= b2 ? ce2 : 0l; o += a >= b3 ? ce3 : 0l; o += a >= b4 ? ce4 : 0l;
+    return pc0 + o;
+  };
+  auto box_ptr = [&](int a) -> const unsigned char* {      // address of anchor a's four box bytes
+    long o = 4l * a;
+    o += a >= b1 ? be1 : 0l; o += a >= b2 ? be2 : 0l; o += a >= b3 ? be3 : 0l; o += a >= b4 ? be4 : 0l;
+    return pb0 + o;
+  };
+  auto whole = [&](int i, const unsigned char* src) -> bool {   // dword i: inside one level, dword-aligned, entirely below A
+    const int a = 4 * i;
+    return level_of(a) == level_of(a + 3) && a + 3 < A && (((unsigned long)src) & 3ul) == 0;
+  };
+  auto patch = [&](int i) -> unsigned {                      // the same dword assembled from single bytes
+    unsigned w = 0;
+    for (int e = 0; e < 4; e++)
+      if (4 * i + e < A) w |= (unsigned)*cls_ptr(4 * i + e) << (8 * e);
+    return w;
+  };
+  {
+    unsigned w[PS];
+#pragma unroll
+    for (int k = 0; k < PS; k++)      // (a dword that will be patched reads the aligned dword around its first byte: inside the arena)
+      w[k] = *(const unsigned*)((unsigned long)cls_ptr(4 * min(tid + NT * k, n4 - 1)) & ~3ul);
+#pragma unroll
+    for (int k = 0; k < PS; k++)
+      if (tid + NT * k < n4) ((unsigned*)cb)[tid + NT * k] = w[k];
+#pragma unroll 1
+    for (int i = tid + NT * PS; i < n4; i += NT) ((unsigned*)cb)[i] = *(const unsigned*)((unsigned long)cls_ptr(4 * i) & ~3ul);
+#pragma unroll 1
+    for (int i = tid; i < n4; i += NT)
+      if (!whole(i, cls_ptr(4 * i))) ((unsigned*)cb)[i] = patch(i);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) hist32[tid + NT * k] = 0;
+  if (tid < 256) {
+    rhist[tid] = 0;
+    s_score[tid] = ((const float*)p.tables)[tid];
+    s_dq[tid] = ((const double*)(p.tables + 1024))[tid];
+    s_ex[tid] = ((const double*)(p.tables + 3072))[tid];
+    s_rank[tid] = ((const signed char*)(p.tables + 5120))[tid];
+  }
   if (tid == 0) { s_nsel = 0; s_done = 0; }
   __syncthreads();
-  // pass 1: histogram of the class bytes
-  for (int l = 0; l < 5; l++) {
-    int nl = p.base[l + 1] - p.base[l];
-    if ((nl & 3) == 0) {  // four class bytes per load (the per-frame base stays dword-aligned)
-      const unsigned* c4 = (const unsigned*)cls[l];
-      for (int i = tid; i < (nl >> 2); i += 256) {
-        const unsigned u = c4[i];
+  POST_STAMP(0);
+  // ---- 2. histogram of the class bytes (bin = byte + 128); a thread keeps its first PS dwords in registers for the candidate passes
+  unsigned u[PS];
 #pragma unroll
-        for (int e = 0; e < 4; e++) atomicAdd(&hist[(int)s_rank[((u >> (8 * e)) & 255u) ^ 128u] + 128], 1);
-      }
-    } else {
-      for (int i = tid; i < nl; i += 256) atomicAdd(&hist[(int)s_rank[(int)cls[l][i] + 128] + 128], 1);
+  for (int k = 0; k < PS; k++) u[k] = ((const unsigned*)cb)[min(tid + NT * k, n4 - 1)] ^ 0x80808080u;
+  {
+    const int copy = tid & 31;
+#pragma unroll
+    for (int k = 0; k < PS; k++) {
+      const int i = tid + NT * k;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (4 * i + e < A) atomicAdd(&hist32[(((u[k] >> (8 * e)) & 255u) << 5) + copy], 1);
+    }
+    for (int i = tid + NT * PS; i < n4; i += NT) {
+      const unsigned w = ((const unsigned*)cb)[i] ^ 0x80808080u;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (4 * i + e < A) atomicAdd(&hist32[(((w >> (8 * e)) & 255u) << 5) + copy], 1);
     }
   }
   __syncthreads();
-  int qcur = 127;   // highest class byte not yet consumed (uniform across the block)
+  {  // bin tid >> 2, copies 8 (tid & 3) .. + 7 (rotated by the bin: consecutive bins start in different banks)
+    const int bin = tid >> 2, part = tid & 3;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c += hist32[(bin << 5) + 8 * part + ((k + bin) & 7)];
+    if (c) atomicAdd(&rhist[(int)s_rank[bin] + 128], c);
+  }
+  __syncthreads();      // (hist32 is dead from here on: its bytes hold keys, sorted keys, boxes and scores)
+  POST_STAMP(1);
+  int qcur = 127;   // highest rank byte not yet consumed (uniform across the block)
   int seg0 = 0;     // for an oversized bin: next anchor index to scan
   while (true) {
-    if (tid == 0) {
-      // pick the next range of score bins (and, for one oversized bin, a slice of anchor indices)
-      int q = qcur;
-      while (q >= p.qmin && hist[q + 128] == 0) q--;
-      if (q < p.qmin) {
-        s_done = 1;
-      } else if (hist[q + 128] > POST_CAP) {
-        s_qhi = q; s_qlo = q; s_i0 = seg0; s_i1 = min(seg0 + POST_CAP, p.A);
-      } else {
-        int tot = 0, qlo = q;
-        while (qlo >= p.qmin && tot + hist[qlo + 128] <= POST_CAP && tot < 256) { tot += hist[qlo + 128]; qlo--; }
-        s_qhi = q; s_qlo = qlo + 1; s_i0 = 0; s_i1 = p.A;
+    // ---- 3. next range of ranks: lane L of wavefront 0 owns the ranks 127 - 4L .. 124 - 4L (descending positions t = 4L + j)
+    if (wave == 0) {
+      int v[4], before[4];
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = 127 - (4 * lane + j);
+        v[j] = (r <= qcur && r >= p.qmin) ? rhist[r + 128] : 0;
+        before[j] = sum;
+        sum += v[j];
       }
-      s_n = 0;
+      const int excl = wave_incl_scan_i(sum) - sum;
+      int ffail = 4, ftop = 4;              // first failing / first non-empty position of this lane (4: none)
+#pragma unroll
+      for (int j = 3; j >= 0; j--) {
+        const int r = 127 - (4 * lane + j);
+        const int bf = excl + before[j];
+        const bool ok = r > qcur || (r >= p.qmin && bf < 256 && bf + v[j] <= POST_CAP);
+        if (!ok) ffail = j;
+        if (v[j] > 0) ftop = j;
+      }
+      const int lf = wave_first_lane(ffail < 4), lt = wave_first_lane(ftop < 4);
+      const int tfail = lf < 64 ? 4 * lf + __builtin_amdgcn_readlane(ffail, lf) : 256;
+      const int ttop = lt < 64 ? 4 * lt + __builtin_amdgcn_readlane(ftop, lt) : 256;
+      if (lane == 0) {
+        if (ttop >= 256) {
+          s_done = 1;                                   // nothing left at or above the score threshold
+        } else if (tfail <= ttop) {                     // the first non-empty bin alone exceeds POST_CAP: a slice of anchor indices
+          s_qhi = 127 - ttop; s_qlo = 127 - ttop; s_i0 = seg0; s_i1 = min(seg0 + POST_CAP, A);
+        } else {
+          s_qhi = 127 - ttop; s_qlo = 128 - tfail; s_i0 = 0; s_i1 = A;
+        }
+        s_blo = 255; s_bhi = 0;
+      }
     }
     __syncthreads();
+    POST_STAMP(2);
     if (s_done) break;
     const int qhi = s_qhi, qlo = s_qlo, i0 = s_i0, i1 = s_i1;
-    // pass 2: collect candidate keys = (127 - q) << 16 | anchor  (ascending key = score desc, anchor asc)
-    for (int l = 0; l < 5; l++) {
-      int lo = max(i0, p.base[l]), hi = min(i1, p.base[l + 1]);
-      const int nl = p.base[l + 1] - p.base[l];
-      if ((nl & 3) == 0 && ((lo - p.base[l]) & 3) == 0) {
-        const unsigned* c4 = (const unsigned*)(cls[l] + (lo - p.base[l]));
-        const int n4 = (hi - lo) >> 2;
-        for (int i4 = tid; i4 < n4; i4 += 256) {
-          const unsigned u = c4[i4];
+    if (tid < 256) {  // class-byte bins whose rank lies in [qlo, qhi]: a contiguous range (the LOGISTIC table is monotone)
+      const int r = (int)s_rank[tid];
+      const unsigned long long m = __ballot(r >= qlo && r <= qhi);
+      if (lane == 0 && m) {
+        atomicMin(&s_blo, 64 * wave + __ffsll((long long)m) - 1);
+        atomicMax(&s_bhi, 64 * wave + 63 - __clzll((long long)m));
+      }
+    }
+    __syncthreads();
+    POST_STAMP(11);
+    // ---- 4. candidates: count, block-wide exclusive scan, write.  The range test runs on four class bytes at a time (SWAR):
+    // d = (x - blo) mod 256 per byte, hit = d <= span per byte, as bit 7 of each byte of `hm`; candidates are about 1 % of the anchors,
+    // so the per-candidate work (below) is rare and the per-dword work is what counts.
+    {
+      constexpr unsigned H = 0x80808080u;
+      const unsigned LO7 = ((unsigned)s_blo * 0x01010101u) & ~H, NLO = ~((unsigned)s_blo * 0x01010101u);
+      const unsigned SP = (unsigned)(s_bhi - s_blo) * 0x01010101u;
+      const bool fullrange = i0 == 0 && i1 == A;
+      auto hits = [&](unsigned x, int i) -> unsigned {
+        const unsigned d = ((x | H) - LO7) ^ ((x ^ NLO) & H);             // bytewise x - blo
+        const unsigned t = (SP | H) - (d & ~H);                           // bit 7: low seven bits of span >= those of d
+        unsigned m = ((SP & ~d) | (~(SP ^ d) & t)) & H;                   // bytewise d <= span
+        if (fullrange) {
+          if (i == n4 - 1 && (A & 3)) m &= (1u << (8 * (A & 3))) - 1u;    // bytes past the last anchor
+        } else {                                                          // a slice [i0, i1) of anchor indices (oversized bin)
+          const int lo = min(max(i0 - 4 * i, 0), 4), hi = min(max(i1 - 4 * i, 0), 4);
+          m &= (unsigned)(((1ull << (8 * hi)) - 1ull) & ~((1ull << (8 * lo)) - 1ull));
+        }
+        return m;
+      };
+      unsigned hm[PS];
+      int cnt = 0;
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const int q = (int)s_rank[((u >> (8 * e)) & 255u) ^ 128u];
-            if (q >= qlo && q <= qhi) {
-              int pos = atomicAdd(&s_n, 1);
-              keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)(lo + 4 * i4 + e);
-            }
-          }
+      for (int k = 0; k < PS; k++) {
+        hm[k] = tid + NT * k < n4 ? hits(u[k], tid + NT * k) : 0u;
+        cnt += __popc(hm[k]);
+      }
+#pragma unroll 1
+      for (int i = tid + NT * PS; i < n4; i += NT) cnt += __popc(hits(((const unsigned*)cb)[i] ^ H, i));
+      const int incl = wave_incl_scan_i(cnt);
+      if (lane == 63) s_wtot[wave] = incl;
+      __syncthreads();
+      POST_STAMP(12);
+      int pos = incl - cnt;
+#pragma unroll
+      for (int w = 0; w < NT / 64; w++) pos += (w < wave) ? s_wtot[w] : 0;
+      if (tid == NT - 1) s_n = pos + cnt;
+      // keys = (127 - rank) << 16 | anchor  (ascending key = score desc, anchor asc)
+      auto emit = [&](unsigned x, unsigned m, int i) {
+#pragma unroll 1
+        while (m) {
+          const int e = (__ffs((int)m) - 1) >> 3;
+          m &= m - 1u;
+          keys[pos++] = ((unsigned)(127 - (int)s_rank[(x >> (8 * e)) & 255u]) << 16) | (unsigned)(4 * i + e);
         }
-        for (int i = lo + 4 * n4 + tid; i < hi; i += 256) {
-          int q = s_rank[(int)cls[l][i - p.base[l]] + 128];
-          if (q >= qlo && q <= qhi) {
-            int pos = atomicAdd(&s_n, 1);
-            keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)i;
-          }
-        }
-      } else {
-        for (int i = lo + tid; i < hi; i += 256) {
-          int q = s_rank[(int)cls[l][i - p.base[l]] + 128];
-          if (q >= qlo && q <= qhi) {
-            int pos = atomicAdd(&s_n, 1);
-            keys[pos] = ((unsigned)(127 - q) << 16) | (unsigned)i;
-          }
-        }
+      };
+#pragma unroll
+      for (int k = 0; k < PS; k++)
+        if (hm[k]) emit(u[k], hm[k], tid + NT * k);
+#pragma unroll 1
+      for (int i = tid + NT * PS; i < n4; i += NT) {
+        const unsigned x = ((const unsigned*)cb)[i] ^ H;
+        const unsigned m = hits(x, i);
+        if (m) emit(x, m, i);
       }
     }
     __syncthreads();
     const int n = s_n;
-    int n2 = 64;
-    while (n2 < n) n2 <<= 1;
-    for (int i = n + tid; i < n2; i += 256) keys[i] = 0xFFFFFFFFu;
+    const bool fast = n <= POST_FAST;
+    const unsigned* sk = fast ? skeys : keys;
+    if (fast) {
+      const int nq = (n + 3) >> 2;
+      if (tid < 4 * nq - n) keys[n + tid] = 0xFFFFFFFFu;
+    } else {
+      int n2 = 2048;
+      for (int i = n + tid; i < n2; i += NT) keys[i] = 0xFFFFFFFFu;
+    }
     __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < n2; i += 256) {
-          int ixj = i ^ j;
-          if (ixj > i) {
-            unsigned a = keys[i], c = keys[ixj];
-            bool up = (i & k) == 0;
-            if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
-          }
+    POST_STAMP(3);
+    if (fast) {
+      // counting sort: position of a key = number of smaller keys (keys are unique: the anchor index is part of them); the keys to
+      // compare with are dealt to `parts` threads per key, their partial counts meet in LDS (the box region, not yet in use)
+      const int nq = (n + 3) >> 2;
+      const int parts = n > 0 ? min(NT / n, 4) : 1;
+      int* partial = (int*)lbox;
+      if (tid < parts * n) {
+        const int m = tid % n, part = tid / n;
+        const unsigned mine = keys[m];
+        int r = 0;
+#pragma unroll 4
+        for (int j = part * nq / parts; j < (part + 1) * nq / parts; j++) {
+          const uint4 k4 = ((const uint4*)keys)[j];
+          r += (k4.x < mine) + (k4.y < mine) + (k4.z < mine) + (k4.w < mine);
         }
-        __syncthreads();
+        partial[part * POST_FAST + m] = r;
       }
-    // greedy suppression by wavefront 0
-    if (tid < 64) {
+      __syncthreads();
+      if (tid < n) {
+        int r = partial[tid];
+        for (int q = 1; q < parts; q++) r += partial[q * POST_FAST + tid];
+        skeys[r] = keys[tid];
+      }
+      __syncthreads();
+    } else {
+      const int n2 = 2048;
+      for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = tid; i < n2; i += NT) {
+            int ixj = i ^ j;
+            if (ixj > i) {
+              unsigned a = keys[i], c = keys[ixj];
+              bool up = (i & k) == 0;
+              if ((a > c) == up) { keys[i] = c; keys[ixj] = a; }
+            }
+          }
+          __syncthreads();
+        }
+    }
+    POST_STAMP(4);
+#ifdef VBT_POST_PROF
+    if (tid == 0 && blockIdx.x == 0) { atomicAdd(&g_post_prof[8], 1ull); atomicAdd(&g_post_prof[9], (unsigned long long)n); }
+#endif
+    // DecodeCenterSizeBoxes (detection_postprocess.cc): double intermediates (one mul, one add: no contraction),
+    // one rounding to float per quantity, then float corner arithmetic
+    auto decode = [&](unsigned key, float& sc) -> float4 {
+      const int a = (int)(key & 0xFFFFu);
+      const int q = 127 - (int)(key >> 16);
+      const unsigned bq = *(const unsigned*)box_ptr(a);
+      const float4 an = *(const float4*)(p.anchors + (long)a * 4);
+      const float yc = (float)(s_dq[(int)((bq & 255u) ^ 128u)] * (double)an.z + (double)an.x);
+      const float xc = (float)(s_dq[(int)(((bq >> 8) & 255u) ^ 128u)] * (double)an.w + (double)an.y);
+      const float hh = (float)(0.5 * s_ex[(int)(((bq >> 16) & 255u) ^ 128u)] * (double)an.z);
+      const float hw = (float)(0.5 * s_ex[(int)((bq >> 24) ^ 128u)] * (double)an.w);
+      sc = s_score[q + 128];
+      return make_float4(yc - hh, xc - hw, yc + hh, xc + hw);
+    };
+    // ---- 5. fast path: every candidate of the round decoded at once
+    if (fast) {
+      if (tid < n) {
+        float sc;
+        lbox[tid] = decode(skeys[tid], sc);
+        lsc[tid] = sc;
+      }
+      __syncthreads();
+    }
+    POST_STAMP(13);
+    // ---- 6. greedy suppression by wavefront 0 (IoU as in detection_postprocess.cc: 0 when either area is not positive; the
+    // areas of the candidates and of the selected boxes are computed once)
+    if (wave == 0) {
+      float* selarea = (float*)(sv + 32);
+      auto sup = [&](float4 sb, float sa, float4 cx, float ca) -> bool {
+        const float iy0 = fmaxf(sb.x, cx.x), ix0 = fmaxf(sb.y, cx.y);
+        const float iy1 = fminf(sb.z, cx.z), ix1 = fminf(sb.w, cx.w);
+        const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+        return sa > 0.0f && ca > 0.0f && inter / (sa + ca - inter) > p.iou_thr;
+      };
       int nsel = s_nsel;
       for (int base = 0; base < n && nsel < p.max_det; base += 64) {
-        int ci = base + tid;
+        int ci = base + lane;
         bool alive = ci < n;
         float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
         float sc = 0.f;
         if (alive) {
-          unsigned key = keys[ci];
-          int a = (int)(key & 0xFFFFu);
-          int q = 127 - (int)(key >> 16);
-          int l = 0;
-#pragma unroll
-          for (int t = 1; t < 5; t++) l += (a >= p.base[t]) ? 1 : 0;
-          unsigned bq = *(const unsigned*)(box[l] + (long)(a - p.base[l]) * 4);
-          float4 an = *(const float4*)(p.anchors + (long)a * 4);
-          // DecodeCenterSizeBoxes (detection_postprocess.cc): double intermediates (one mul, one add: no contraction),
-          // one rounding to float per quantity, then float corner arithmetic
-          float yc = (float)(s_dq[(int)((bq & 255u) ^ 128u)] * (double)an.z + (double)an.x);
-          float xc = (float)(s_dq[(int)(((bq >> 8) & 255u) ^ 128u)] * (double)an.w + (double)an.y);
-          float hh = (float)(0.5 * s_ex[(int)(((bq >> 16) & 255u) ^ 128u)] * (double)an.z);
-          float hw = (float)(0.5 * s_ex[(int)((bq >> 24) ^ 128u)] * (double)an.w);
-          bx = make_float4(yc - hh, xc - hw, yc + hh, xc + hw);
-          sc = s_score[q + 128];
-          for (int s = 0; s < nsel; s++)
-            if (iou_box(selbox[s], bx) > p.iou_thr) { alive = false; break; }
+          if (fast) { bx = lbox[ci]; sc = lsc[ci]; }
+          else bx = decode(sk[ci], sc);
         }
+        const float area = (bx.z - bx.x) * (bx.w - bx.y);
+        if (alive)
+          for (int s = 0; s < nsel; s++)
+            if (sup(selbox[s], selarea[s], bx, area)) { alive = false; break; }
         while (nsel < p.max_det) {
-          unsigned long long mask = __ballot(alive);
+          const unsigned long long mask = __ballot(alive);
           if (mask == 0ull) break;
-          int j = __ffsll((long long)mask) - 1;
+          const int j = __ffsll((long long)mask) - 1;     // wave-uniform: the lane's values come over the scalar path
           float4 sb;
-          sb.x = __shfl(bx.x, j); sb.y = __shfl(bx.y, j); sb.z = __shfl(bx.z, j); sb.w = __shfl(bx.w, j);
-          float ss = __shfl(sc, j);
-          if (tid == 0) {
+          sb.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.x), j));
+          sb.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.y), j));
+          sb.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.z), j));
+          sb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.w), j));
+          const float ss = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), j));
+          const float sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(area), j));
+          if (lane == 0) {
             selbox[nsel] = sb;
+            selarea[nsel] = sa;
             float* bo = boxes + (b * p.max_det + nsel) * 4;
             bo[0] = sb.x; bo[1] = sb.y; bo[2] = sb.z; bo[3] = sb.w;
             scores[b * p.max_det + nsel] = ss;
@@ -817,26 +1050,31 @@ __global__ __launch_bounds__(256) void postprocess_kernel(PostArgs p, float* __r
           }
           __threadfence_block();  // selbox[] is read by the other lanes of this wavefront
           nsel++;
-          if (tid == j) alive = false;
-          else if (alive && iou_box(sb, bx) > p.iou_thr) alive = false;
+          if (lane == j) alive = false;
+          else if (alive && sup(sb, sa, bx, area)) alive = false;
         }
       }
-      if (tid == 0) s_nsel = nsel;
+      if (lane == 0) s_nsel = nsel;
     }
     __syncthreads();
+    POST_STAMP(5);
     if (s_nsel >= p.max_det) break;
-    if (qhi == qlo && hist[qhi + 128] > POST_CAP && i1 < p.A) { seg0 = i1; qcur = qhi; }
+    if (qhi == qlo && rhist[qhi + 128] > POST_CAP && i1 < A) { seg0 = i1; qcur = qhi; }
     else { seg0 = 0; qcur = qlo - 1; }
     __syncthreads();
   }
   const int nsel = s_nsel;
-  for (int s = nsel + tid; s < p.max_det; s += 256) {
+  for (int s = nsel + tid; s < p.max_det; s += NT) {
     float* bo = boxes + (b * p.max_det + s) * 4;
     bo[0] = bo[1] = bo[2] = bo[3] = 0.0f;
     scores[b * p.max_det + s] = 0.0f;
     classes[b * p.max_det + s] = 0.0f;
   }
   if (tid == 0) counts[b] = nsel;
+  POST_STAMP(6);
+#ifdef VBT_POST_PROF
+  if (tid == 0 && blockIdx.x == 0) atomicAdd(&g_post_prof[10], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

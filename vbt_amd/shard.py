@@ -40,9 +40,16 @@ def run_schedule(lengths, n_slots, max_run=None):
     step hands each unfinished clip a RUN of consecutive frames, the slots being dealt in proportion to the frames the clips
     have left (largest remainders first, ties to the lower clip), so that every slot of every step but the last carries a
     frame and all clips end together - the sequential OC-SORT walk of a step is then as short as it can be
-    (max run = ceil(n_slots * longest / total)).  max_run caps the frames of one clip per step.
+    (a clip's run in a step is at most ceil(n_slots * frames it has left / frames left in all) + 1: its quota rounded
+    down plus one spare slot).  max_run (>= 1) caps the frames of one clip per step.
     Returns a list of steps; a step is a list of (clip, slot0, n_frames, frame0) with frame0 1-based."""
+    if int(n_slots) < 1:
+        raise ValueError("run_schedule: n_slots must be at least 1")
+    if max_run is not None and int(max_run) < 1:
+        raise ValueError("run_schedule: max_run must be at least 1 (a clip that may take no frame never ends)")
     left = np.asarray(lengths, np.int64).copy()
+    if (left < 0).any():
+        raise ValueError("run_schedule: negative clip length")
     done = np.zeros_like(left)
     steps = []
     while left.sum() > 0:

@@ -425,11 +425,26 @@ class Pipeline:
             if len(frames) != len(runs):
                 raise ValueError("one source tensor per run")
             shp = tuple(frames[0].shape[1:])
+            dev0 = frames[0].device
+            for i, (src, r) in enumerate(zip(frames, ra)):
+                # raw pointers base + f * frame_bytes go to the gather kernel / the copies: a short, strided or differently
+                # shaped source would make them read past its allocation
+                if src.dtype != torch.uint8 or src.dim() != 4 or tuple(src.shape[1:]) != shp or not src.is_contiguous():
+                    raise ValueError(f"step_runs: source {i} must be a contiguous uint8 tensor [n_frames, {shp[0]}, {shp[1]}, {shp[2]}]")
+                if int(src.shape[0]) < r.n_frames:
+                    raise ValueError(f"step_runs: source {i} holds {int(src.shape[0])} frames, its run needs {r.n_frames}")
+                if src.device != dev0:
+                    raise ValueError(f"step_runs: source {i} is on {src.device}, source 0 on {dev0}")
+            used = np.zeros(B, bool)
+            for r in ra:
+                used[r.slot0:r.slot0 + r.n_frames] = True
+            if not used.all():
+                raise ValueError("step_runs: the runs leave a hole in the detector batch")
             stage_j = j = self._stage_idx % len(self._stage)
             self._stage_idx += 1
             st = self._staging(j, (self.n,) + shp)
             fb = int(np.prod(shp))
-            on_host = frames[0].device.type == "cpu"
+            on_host = dev0.type == "cpu"
             if on_host:
                 C = self._copy_stream
                 C.wait_event(self._ev_in[k])
@@ -444,15 +459,21 @@ class Pipeline:
             else:
                 if self._stage_free[j] is not None:
                     S.wait_event(self._stage_free[j])
-                ptrs = (ctypes.c_void_p * B)()
-                for src, r in zip(frames, ra):
-                    src.record_stream(S)
-                    base = src.data_ptr()
-                    for f in range(r.n_frames):
-                        ptrs[r.slot0 + f] = base + f * fb
-                if any(not p for p in ptrs):
-                    raise ValueError("step_runs: the runs leave a hole in the detector batch")
-                _lib.check(L.vbt_gather_frames(st.data_ptr(), ptrs, B, fb, S.cuda_stream))
+                if fb % 16 == 0 and all(src.data_ptr() % 16 == 0 for src in frames):
+                    ptrs = (ctypes.c_void_p * B)()
+                    for src, r in zip(frames, ra):
+                        src.record_stream(S)
+                        base = src.data_ptr()
+                        for f in range(r.n_frames):
+                            ptrs[r.slot0 + f] = base + f * fb
+                    _lib.check(L.vbt_gather_frames(st.data_ptr(), ptrs, B, fb, S.cuda_stream))
+                else:
+                    # a frame size that is not a multiple of 16 bytes (any source resolution is allowed): the gather kernel
+                    # moves 16-byte pieces, so the batch is assembled by one device copy per run instead
+                    with torch.cuda.stream(S):
+                        for src, r in zip(frames, ra):
+                            src.record_stream(S)
+                            st[r.slot0:r.slot0 + r.n_frames].copy_(src[:r.n_frames], non_blocking=True)
             frames_ptr = st.data_ptr()
         elif hasattr(frames, "data_ptr"):
             if frames.device.type == "cpu":
