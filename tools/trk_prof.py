@@ -34,10 +34,10 @@ v = list(out)
 steps = max(v[8], 1)
 names = ["predict", "cost matrix", "assignment", "unmatched lists (after the matched updates)", "second association: rest", "update(None) + births", "emission + deletion",
          None, None, None, None, "matched Kalman updates", "second association: cost entries", "second association: assignment", "second association: recovered updates"]
-print(f"steps {steps}  mean detections {v[9] / steps:.2f}  mean live trackers {v[10] / steps:.2f}   (s_memtime ticks = 100 MHz: 10 ns)")
+print(f"steps {steps}  mean detections {v[9] / steps:.2f}  mean live trackers {v[10] / steps:.2f}   (s_memtime counts shader cycles: 2.4 GHz when the kernel runs alone)")
 tot = sum(v[i] for i, nme in enumerate(names) if nme)
 for i, nme in enumerate(names):
     if not nme:
         continue
-    print(f"  {nme:52s} {v[i] / steps * 10 / 1000:7.2f} us  {100 * v[i] / tot:5.1f} %")
-print(f"  total                        {tot / steps * 10 / 1000:7.2f} us per stepped frame")
+    print(f"  {nme:52s} {v[i] / steps:8.0f} cycles = {v[i] / steps / 2400:6.2f} us  {100 * v[i] / tot:5.1f} %")
+print(f"  total                        {tot / steps:8.0f} cycles = {tot / steps / 2400:6.2f} us per stepped frame")

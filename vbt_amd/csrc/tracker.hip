@@ -246,6 +246,52 @@ __device__ inline double diou_xyxy(const double* a, const double* b) {
 // selection rule (lowest cost; among equals the LAST unassigned column scanned, else the first),
 // same dual updates and the same floating-point expression ((minVal + c) - u) - v.
 // ------------------------------------------------------------------------------------------
+// Wave-wide reductions on the DPP path (row shifts inside rows of 16 lanes, then the GFX9 row broadcasts; lane 63 ends with the
+// result, which comes back over the scalar path): six dependent steps of two or three VALU instructions instead of six shuffles
+// through the LDS crossbar per 32-bit half.  The values met are the ones the shuffles met, so every result is unchanged.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double old, double x) {
+  const unsigned long long o = (unsigned long long)__double_as_longlong(old), v = (unsigned long long)__double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)v, CTRL, ROWMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(v >> 32), CTRL, ROWMASK, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double bcast63_f64(double x) {
+  const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_min_f64(double x) {
+  const double I = __builtin_inf();
+  x = fmin(x, dpp_f64<0x111, 0xf>(I, x));
+  x = fmin(x, dpp_f64<0x112, 0xf>(I, x));
+  x = fmin(x, dpp_f64<0x114, 0xf>(I, x));
+  x = fmin(x, dpp_f64<0x118, 0xf>(I, x));
+  x = fmin(x, dpp_f64<0x142, 0xa>(I, x));
+  x = fmin(x, dpp_f64<0x143, 0xc>(I, x));
+  return bcast63_f64(x);
+}
+__device__ __forceinline__ double wave_max_f64(double x) {
+  const double I = -__builtin_inf();
+  x = fmax(x, dpp_f64<0x111, 0xf>(I, x));
+  x = fmax(x, dpp_f64<0x112, 0xf>(I, x));
+  x = fmax(x, dpp_f64<0x114, 0xf>(I, x));
+  x = fmax(x, dpp_f64<0x118, 0xf>(I, x));
+  x = fmax(x, dpp_f64<0x142, 0xa>(I, x));
+  x = fmax(x, dpp_f64<0x143, 0xc>(I, x));
+  return bcast63_f64(x);
+}
+__device__ __forceinline__ int wave_max_i32(int x) {
+  constexpr int I = -2147483647 - 1;
+  x = max(x, __builtin_amdgcn_update_dpp(I, x, 0x111, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(I, x, 0x112, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(I, x, 0x114, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(I, x, 0x118, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(I, x, 0x142, 0xa, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(I, x, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(x, 63);
+}
+
 struct LapShared {
   double u[MAXT];
   double spc[MAXT];
@@ -262,9 +308,7 @@ __device__ void lap_solve(const double* C, int ld, bool tr, int nr, int nc, int*
     // ends at the cheapest column; among equal costs it takes the LAST one it scans, and it scans remaining[] = nc-1 ... 0,
     // i.e. the lowest column index.  No dual update can change a one-row result.
     double c = lane < nc ? (tr ? C[lane * ld] : C[lane]) : INF;
-    double lowest = c;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lowest = fmin(lowest, __shfl_xor(lowest, o));
+    const double lowest = wave_min_f64(c);
     const unsigned long long cand = __ballot(lane < nc && c == lowest);
     if (lane == 0) row2col[0] = __ffsll((long long)cand) - 1;
     __syncthreads();
@@ -294,16 +338,13 @@ __device__ void lap_solve(const double* C, int ld, bool tr, int nr, int nc, int*
         double r = ((minVal + c) - ui) - v;
         if (r < spc) { S.path[lane] = i; spc = r; }
       }
-      double lowest = active ? spc : INF;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) lowest = fmin(lowest, __shfl_xor(lowest, o));
+      const double lowest = wave_min_f64(active ? spc : INF);
       const bool cand = active && spc == lowest;
       const unsigned long long un = __ballot(cand && r4c == -1);
       int key;  // choose: unassigned candidates -> max position, else min position
       if (un) key = (cand && r4c == -1) ? pos : -1;
       else key = cand ? -pos : -(1 << 20);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
+      key = wave_max_i32(key);
       const int index = un ? key : -key;
       minVal = lowest;
       const int j = S.remaining[index];
@@ -463,9 +504,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   TRK_MARK(1);   // cost matrix
   if (lane < MAXD) { sh.d2t[lane] = -1; sh.rej[lane] = 0; sh.taken[lane] = 0; }
   __syncthreads();
-  int maxcol = colsum;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) maxcol = max(maxcol, __shfl_xor(maxcol, o));
+  const int maxcol = wave_max_i32(colsum);
   int maxrow = 0;
   for (int d = 0; d < nd; d++) {
     unsigned long long m = __ballot(lane < T && sh.iou[d][lane] > p.iou_thr);
@@ -491,7 +530,8 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   }
   TRK_MARK(2);   // assignment
   // d2t[d]: tracker position the solver paired with detection d (-1 none); rej[d]: pair rejected (IoU < thr)
-  if (lane < T && my_det >= 0) {
+  const bool was_paired = lane < T && my_det >= 0;   // the solver paired this lane's tracker with a detection (accepted or not)
+  if (was_paired) {
     sh.d2t[my_det] = lane;
     if (sh.iou[my_det][lane] < p.iou_thr) { sh.rej[my_det] = 1; my_det = -1; }
   }
@@ -501,17 +541,18 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   // unmatched lists in the reference's order (it matters: the second association sees exact ties):
   //   detections: never paired ascending, then rejected pairs in matched (= detection) order
   //   trackers  : never paired ascending, then the trackers of the rejected pairs in the same order
-  if (lane == 0) {
-    unsigned long long paired = 0ull;
-    int n = 0, m = 0;
-    for (int d = 0; d < nd; d++) {
-      if (sh.d2t[d] < 0) sh.um_d[n++] = d;
-      else paired |= 1ull << sh.d2t[d];
-    }
-    for (int t = 0; t < T; t++) if (!((paired >> t) & 1ull)) sh.um_t[m++] = t;
-    for (int d = 0; d < nd; d++) if (sh.d2t[d] >= 0 && sh.rej[d]) { sh.um_d[n++] = d; sh.um_t[m++] = sh.d2t[d]; }
-    sh.n_um_d = n;
-    sh.n_um_t = m;
+  // lane = detection for the detection list and the rejected pairs, lane = tracker for the never-paired trackers: positions are
+  // population counts of ballots (the lists used to be walked by lane 0, one dependent LDS round trip per element)
+  {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int dt_ = lane < nd ? sh.d2t[lane] : 0;
+    const bool un_d = lane < nd && dt_ < 0, rj_d = lane < nd && dt_ >= 0 && sh.rej[lane] != 0;
+    const unsigned long long mU = __ballot(un_d), mR = __ballot(rj_d), mT = __ballot(lane < T && !was_paired);
+    const int nU = __popcll(mU), nR = __popcll(mR), nT = __popcll(mT);
+    if (un_d) sh.um_d[__popcll(mU & below)] = lane;
+    if (rj_d) { const int q = __popcll(mR & below); sh.um_d[nU + q] = lane; sh.um_t[nT + q] = dt_; }
+    if (lane < T && !was_paired) sh.um_t[__popcll(mT & below)] = lane;
+    if (lane == 0) { sh.n_um_d = nU + nR; sh.n_um_t = nT + nR; }
   }
   __syncthreads();
   TRK_MARK(3);   // matched updates + unmatched lists
@@ -534,8 +575,7 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
         mx = fmax(mx, v);
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    mx = wave_max_f64(mx);
     __syncthreads();
     TRK_MARK(12);  // second association: cost entries
     if (mx > p.iou_thr) {
@@ -559,10 +599,12 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
       recovered = true;
       __syncthreads();
       TRK_MARK(14);  // second association: recovered tracks' Kalman updates (incl. the re-update over the gap)
-      if (lane == 0) {  // np.setdiff1d: sorted ascending
-        int n = 0;
-        for (int d = 0; d < nd; d++) if ((sh.d2t[d] < 0 || sh.rej[d]) && !sh.taken[d]) sh.um_d[n++] = d;
-        sh.n_um_d = n;
+      {  // np.setdiff1d: sorted ascending (lane = detection)
+        const bool left = lane < nd && (sh.d2t[lane] < 0 || sh.rej[lane] != 0) && !sh.taken[lane];
+        const unsigned long long mL = __ballot(left);
+        __syncthreads();     // every lane has read the old list entries it needs (um_d is rewritten in place)
+        if (left) sh.um_d[__popcll(mL & ((1ull << lane) - 1ull))] = lane;
+        if (lane == 0) sh.n_um_d = __popcll(mL);
       }
       __syncthreads();
     }
