@@ -30,6 +30,7 @@ extern "C" {
 #define VBT_MODEL_TILE128 16384       /* heuristic plan: 128-pixel tiles in the fused MBConv blocks that allow them */
 #define VBT_MODEL_NO_BAND 8192        /* do not use the row-band SeparableConv kernel of the BiFPN nodes / head layers */
 #define VBT_MODEL_NO_EXPDW 4096       /* do not use the whole-image expand+depthwise kernel of the low-resolution MBConv blocks */
+#define VBT_MODEL_NO_PW_MERGE 32768    /* keep the P6 conv, its pools and the lateral convs of the first BiFPN cell as separate launches */
 #define VBT_MODEL_NO_AUTOTUNE 8     /* keep the heuristic plan (most fused alternative, default kernel variants) */
 
 /* ------------------------------------------------------------------ graph introspection -------------------------------- */

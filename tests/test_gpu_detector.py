@@ -25,8 +25,9 @@ def oracle_run(oracle_lib, model_path, frames):
 # every group (incl. whole BiFPN nodes; low-resolution MBConv blocks as whole-image expand+depthwise + projection GEMM
 # with the residual in its epilogue; BiFPN nodes and head layers on row bands); 8|4096 / 8|8192 = the same with those
 # blocks / layers on the 64-pixel tile kernel; 8|128 = one launch per head layer and level; 8|2 = dw+project fused,
-# expand separate; 8|16 = no BiFPN node fusion; 0 = autotuned mix (whatever is fastest on this GPU)
-@pytest.mark.parametrize("flags", [1, 8, 8 | 4096 | 8192, 8 | 8192, 8 | 2, 8 | 16, 8 | 128 | 8192, 8 | 128, 8 | 256, 8 | 512 | 4096, 8 | 2048 | 4096, 8 | 16384, 8 | 16384 | 2048, 0])
+# expand separate; 8|16 = no BiFPN node fusion; 8|32768 = the P6 conv, its two max pools and the five lateral convs as eight launches instead
+# of one (pw_multi_kernel); 0 = autotuned mix (whatever is fastest on this GPU)
+@pytest.mark.parametrize("flags", [1, 8, 8 | 4096 | 8192, 8 | 8192, 8 | 2, 8 | 16, 8 | 128 | 8192, 8 | 128, 8 | 256, 8 | 512 | 4096, 8 | 2048 | 4096, 8 | 16384, 8 | 16384 | 2048, 8 | 32768, 0])
 def test_every_tensor_bit_exact(model_path, frames, oracle_run, flags):
     """Every plan must reproduce the oracle bit for bit: all 250 tensors when unfused, every tensor that still
     reaches HBM otherwise (fused MBConv / SeparableConv blocks keep their intermediates in LDS)."""
@@ -42,6 +43,7 @@ def test_every_tensor_bit_exact(model_path, frames, oracle_run, flags):
         assert it.num_launches() == 251 and all(it.materialized(t) for t in range(1, it.num_tensors() - 1))
     if flags == 8:
         assert it.num_launches() < 70
+        assert Interpreter(model_path, max_batch=B, flags=8 | 32768).num_launches() == it.num_launches() + 7   # 6 convs + 2 pools -> 1 launch
     for tid in range(1, it.num_tensors() - 1):
         if not it.materialized(tid):
             continue

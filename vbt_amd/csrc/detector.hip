@@ -1427,6 +1427,75 @@ static int fuse_plan(vbt_model* m) {
   return VBT_OK;
 }
 
+// Pointwise convs that read nothing but tensors already there when the first of them runs are merged into one launch
+// (pw_multi_kernel): in an EfficientDet graph the P6 conv and the five lateral convs of the first BiFPN cell all read backbone
+// outputs.  The anchor is the stand-alone pointwise conv with the most followers; a conv followed by the two 3x3/2 max pools
+// that make P6 and P7 takes them along.  Every merged tensor is still written, by the same arithmetic.
+static bool pwm_mergeable(const vbt_model* m, const Step& s) {
+  if (s.family != F_PW || s.res_op >= 0 || !s.members.empty() || !s.wp64) return false;
+  const OpRec& op = m->ops[s.op];
+  return op.type == OP_PW && m->tensors[op.output].c % 4 == 0 && s.KS64 >= 1;
+}
+static void merge_side_convs(vbt_model* m) {
+  static const bool off = getenv("VBT_NO_PW_MERGE") != nullptr;
+  if (off || (m->flags & (VBT_MODEL_NO_FUSION | VBT_MODEL_NO_PW_MERGE))) return;
+  const int ns = (int)m->steps.size();
+  auto written_from = [&](int tensor, int i0) {   // is `tensor` written by a step at or after i0 ?
+    for (int j = i0; j < ns; j++) {
+      const Step& s = m->steps[j];
+      if (m->ops[s.op].output == tensor) return true;
+      for (const Step& ms : s.members) if (m->ops[ms.op].output == tensor) return true;
+    }
+    return false;
+  };
+  int best = -1;
+  std::vector<int> best_set;
+  for (int i = 0; i < ns; i++) {
+    if (!pwm_mergeable(m, m->steps[i])) continue;
+    std::vector<int> set{i};
+    for (int j = i + 1; j < ns && (int)set.size() < PWM_MAX; j++)
+      if (pwm_mergeable(m, m->steps[j]) && !written_from(m->ops[m->steps[j].op].inputs[0], i)) set.push_back(j);
+    if (set.size() >= best_set.size() && set.size() >= 2) { best = i; best_set = set; }
+  }
+  if (best < 0) return;
+  Step merged = m->steps[best];
+  merged.members.clear();
+  merged.alg_bytes_per_frame = merged.weight_bytes = merged.macs_per_frame = 0;
+  std::vector<char> drop(ns, 0);
+  for (int j : best_set) {
+    merged.members.push_back(m->steps[j]);
+    merged.alg_bytes_per_frame += m->steps[j].alg_bytes_per_frame;
+    merged.weight_bytes += m->steps[j].weight_bytes;
+    merged.macs_per_frame += m->steps[j].macs_per_frame;
+    if (j != best) drop[j] = 1;
+  }
+  // the anchor's pools: steps best + 1 / best + 2 = MAX_POOL 3x3/2 of the anchor's output and of that pool
+  merged.nbp = 0;   // (1: the anchor carries its two pools)
+  if (best + 2 < ns && m->steps[best + 1].family == F_MAXPOOL && m->steps[best + 2].family == F_MAXPOOL) {
+    const OpRec &c = m->ops[m->steps[best].op], &p1 = m->ops[m->steps[best + 1].op], &p2 = m->ops[m->steps[best + 2].op];
+    const TensorRec& to = m->tensors[c.output];
+    const TensorRec& t1 = m->tensors[p1.output];
+    const size_t lds = (size_t)((to.h * to.w * to.c + 15) & ~15) + (size_t)t1.h * t1.w * t1.c;
+    if (p1.inputs[0] == c.output && p2.inputs[0] == p1.output && p1.k == 3 && p1.stride == 2 && p2.k == 3 && p2.stride == 2 &&
+        to.c % 16 == 0 && lds <= 64 * 1024) {
+      merged.nbp = 1;
+      merged.lds_bytes = (int)lds;
+      merged.members.push_back(m->steps[best + 1]);
+      merged.members.push_back(m->steps[best + 2]);
+      for (int k = 1; k <= 2; k++) {
+        merged.alg_bytes_per_frame += m->steps[best + k].alg_bytes_per_frame;
+        drop[best + k] = 1;
+      }
+    }
+  }
+  std::vector<Step> out;
+  for (int i = 0; i < ns; i++) {
+    if (i == best) out.push_back(merged);
+    else if (!drop[i]) out.push_back(m->steps[i]);
+  }
+  m->steps.swap(out);
+}
+
 static void finalize_plan(vbt_model* m) {
   m->steps.clear();
   m->materialized.assign(m->tensors.size(), 1);
@@ -1435,6 +1504,7 @@ static void finalize_plan(vbt_model* m) {
     for (const Step& s : a.steps) m->steps.push_back(s);
     for (int t : a.hidden) m->materialized[t] = 0;
   }
+  merge_side_convs(m);
 }
 
 static int build_plan(vbt_model* m) {
@@ -1660,6 +1730,41 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
       break;
     }
     case F_PW: {
+      if (!s.members.empty()) {   // several convs in one launch (merge_side_convs)
+        if (boff != 0) { set_error("merged pointwise convs: sub-batch streams are not supported (VBT_SUBSTREAMS)"); return VBT_ERR_ARG; }
+        PwMulti pm;
+        memset(&pm, 0, sizeof(pm));
+        const int nconv = (int)s.members.size() - (s.nbp ? 2 : 0);
+        int acc = 0;
+        for (int i = 0; i < nconv; i++) {
+          const Step& ms = s.members[i];
+          const OpRec& pop = m->ops[ms.op];
+          const TensorRec& ti = m->tensors[pop.inputs[0]];
+          const TensorRec& tpo = m->tensors[pop.output];
+          PwProb& q = pm.p[i];
+          q.x = TP(pop.inputs[0]); q.wp = ms.wp64; q.bias = ms.bias; q.mult = ms.mult; q.out = TP(pop.output);
+          q.rq = make_rq(tpo.zero_point, pop.act_min, pop.act_max);
+          q.K = ti.c; q.KS = ms.KS64; q.N = tpo.c; q.NB = ms.NB;
+          pm.start[i] = acc;
+          if (i == 0 && s.nbp) {
+            const OpRec &p1 = m->ops[s.members[nconv].op], &p2 = m->ops[s.members[nconv + 1].op];
+            const TensorRec &t1 = m->tensors[p1.output], &t2 = m->tensors[p2.output];
+            q.M = tpo.h * tpo.w;
+            q.pool1 = TP(p1.output); q.pool2 = TP(p2.output);
+            q.H = tpo.h; q.W = tpo.w; q.H1 = t1.h; q.W1 = t1.w; q.pt1 = p1.pad_t; q.pl1 = p1.pad_l;
+            q.H2 = t2.h; q.W2 = t2.w; q.pt2 = p2.pad_t; q.pl2 = p2.pad_l;
+            acc += B;
+          } else {
+            q.M = B * tpo.h * tpo.w;
+            acc += ((q.M + 63) / 64) * q.NB;
+          }
+        }
+        pm.n = nconv;
+        pm.start[nconv] = acc;
+        for (int i = nconv + 1; i <= PWM_MAX; i++) pm.start[i] = acc;
+        pw_multi_kernel<<<dim3((unsigned)acc), 256, s.nbp ? s.lds_bytes : 0, st>>>(pm);
+        break;
+      }
       // op = the op whose output is written: the conv itself, or the residual ADD evaluated in its epilogue (res_op)
       const OpRec& pop = m->ops[s.res_op >= 0 ? s.p_op : s.op];
       const TensorRec& ti = m->tensors[pop.inputs[0]];

@@ -329,6 +329,135 @@ __global__ __launch_bounds__(256) void pw_d_kernel(const int8_t* __restrict__ x,
   }
 }
 
+__device__ __forceinline__ unsigned max4_s8(unsigned a, unsigned b) {
+  unsigned r = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    int x = (int)(int8_t)(a >> (8 * j)), y = (int)(int8_t)(b >> (8 * j));
+    r |= (unsigned)(max(x, y) & 255) << (8 * j);
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Several independent pointwise convs in ONE launch: the 1x1 "lateral" convs the first BiFPN cell applies to the backbone outputs
+// (P3 x 1, P4 x 2, P5 x 2) and the P6 conv read nothing but backbone tensors, so they need not wait for each other or for the
+// nodes before them - as six launches of 5-11 us they were head and tail of a 3 us kernel each (and six of the 65 launches of
+// a batch-1 forward).  A workgroup = 64 pixels x one 64-channel block of one problem, K streamed as in variant B.
+// The P6 problem can carry the two 3x3/2 max pools that follow it (P6 = pool(conv(P5)), P7 = pool(P6)): then one workgroup owns one
+// image, keeps the conv output in LDS and writes all three tensors.
+// ------------------------------------------------------------------------------------------
+constexpr int PWM_MAX = 8;
+struct PwProb {
+  const int8_t* x;
+  const v4i* wp;
+  const int* bias;
+  const float* mult;
+  int8_t* out;
+  Rq rq;
+  int M, K, KS, N, NB;     // M = pixels of the whole batch (chain: of one image)
+  // chain (pool1 != nullptr): conv output H x W per image, pooled to H1 x W1 (pad pt1 / pl1) and again to H2 x W2
+  int8_t* pool1;
+  int8_t* pool2;
+  int H, W, H1, W1, pt1, pl1, H2, W2, pt2, pl2;
+};
+struct PwMulti {
+  int n;
+  int start[PWM_MAX + 1];   // first workgroup of every problem
+  PwProb p[PWM_MAX];
+};
+
+// 3x3 stride-2 max pool of an int8 [H][W][N] map held in LDS (N % 4 == 0), out-of-map taps skipped (SAME): -> global + optional LDS copy
+__device__ __forceinline__ void pwm_pool(const unsigned char* src, int H, int W, int N, int OH, int OW, int pt, int pl, int8_t* gout,
+                                         unsigned char* lout, int tid) {
+  const int N4 = N >> 2, total = OH * OW * N4;
+  const float rcp_n4 = frcp(N4), rcp_ow = frcp(OW);
+  for (int i = tid; i < total; i += 256) {
+    const int pix = fdiv_small(i, rcp_n4), c4 = i - pix * N4;
+    const int oy = fdiv_small(pix, rcp_ow), ox = pix - oy * OW;
+    unsigned best = 0x80808080u;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++) {
+      const int iy = oy * 2 + ky - pt;
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int ix = ox * 2 + kx - pl;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) best = max4_s8(best, *(const unsigned*)(src + (iy * W + ix) * N + 4 * c4));
+      }
+    }
+    *(unsigned*)(gout + (long)pix * N + 4 * c4) = best;
+    if (lout) *(unsigned*)(lout + pix * N + 4 * c4) = best;
+  }
+}
+
+__global__ __launch_bounds__(256) void pw_multi_kernel(PwMulti pm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pwm_smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < PWM_MAX; i++) pi += (i < pm.n && (int)blockIdx.x >= pm.start[i]) ? 1 : 0;
+  const PwProb& q = pm.p[pi];
+  const int local = blockIdx.x - pm.start[pi];
+  const Epi e{q.bias, q.mult, 0, 0, 0, q.rq};
+  const ResArgs ra{nullptr, AddQ{0, 0, 0, 0, 0, 0, 0}};
+  if (q.pool1 == nullptr) {
+    const int nb = local % q.NB;
+    const long m0 = ((long)(local / q.NB) * 4 + wave) * 16;
+    if (m0 >= q.M) return;
+    const long m = min(m0 + r, (long)q.M - 1);
+    const int8_t* px = q.x + m * q.K + 16 * g;
+    EpiRegs er;
+    load_epi(er, e, ra, m, q.N, nb, g);
+    v4i acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (v4i){0, 0, 0, 0};
+    const v4i* w = q.wp + (long)nb * q.KS * 4 * 64 + lane;
+#pragma unroll 4
+    for (int ks = 0; ks < q.KS; ks++) {
+      const v4i av = ld16(px + 64 * ks);
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[(ks * 4 + t) * 64], av, acc[t], 0, 0, 0);
+    }
+    if (m0 + r < q.M) store_tile_e(acc, er, e, ra, q.out, m0 + r, q.N, nb, g);
+    return;
+  }
+  // chain: image `local`; conv output kept in LDS for the two pools
+  const int HW = q.H * q.W, N = q.N;
+  unsigned char* L0 = pwm_smem;                               // [HW][N]
+  unsigned char* L1 = L0 + ((HW * N + 15) & ~15);             // [H1 * W1][N]
+  const int8_t* xb = q.x + (long)local * HW * q.K;
+  int8_t* ob = q.out + (long)local * HW * N;
+  const int npg = (HW + 15) >> 4;
+  for (int u = wave; u < npg * q.NB; u += 4) {
+    const int pg = u / q.NB, nb = u - pg * q.NB;
+    const int m = min(16 * pg + r, HW - 1);
+    const int8_t* px = xb + (long)m * q.K + 16 * g;
+    EpiRegs er;
+    load_epi(er, e, ra, m, N, nb, g);
+    v4i acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (v4i){0, 0, 0, 0};
+    const v4i* w = q.wp + (long)nb * q.KS * 4 * 64 + lane;
+#pragma unroll 4
+    for (int ks = 0; ks < q.KS; ks++) {
+      const v4i av = ld16(px + 64 * ks);
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[(ks * 4 + t) * 64], av, acc[t], 0, 0, 0);
+    }
+    const int c0 = nb * 64 + 16 * g;
+    if (16 * pg + r < HW && c0 < N) {     // N % 16 == 0 (checked by the planner): a lane's 16 channels are all real
+      const uint4 d = make_uint4(rq_pack_i(acc[0], er.b[0], er.mu[0], e.rq), rq_pack_i(acc[1], er.b[1], er.mu[1], e.rq),
+                                 rq_pack_i(acc[2], er.b[2], er.mu[2], e.rq), rq_pack_i(acc[3], er.b[3], er.mu[3], e.rq));
+      *(uint4*)(ob + (long)m * N + c0) = d;
+      *(uint4*)(L0 + m * N + c0) = d;
+    }
+  }
+  __syncthreads();
+  pwm_pool(L0, q.H, q.W, N, q.H1, q.W1, q.pt1, q.pl1, q.pool1 + (long)local * q.H1 * q.W1 * N, L1, tid);
+  __syncthreads();
+  pwm_pool(L1, q.H1, q.W1, N, q.H2, q.W2, q.pt2, q.pl2, q.pool2 + (long)local * q.H2 * q.W2 * N, nullptr, tid);
+}
+
 // ------------------------------------------------------------------------------------------
 // stem: 3x3 stride-2 conv on the uint8 frame as one 16x16x32 MFMA K-step.  The 27 taps are
 // laid out per lane group g: g<3 -> the first 8 bytes (px0 RGB, px1 RGB, px2 RG) of kernel row g,
@@ -577,16 +706,6 @@ __global__ __launch_bounds__(256) void add_kernel(const int8_t* __restrict__ xa,
   } else {
     for (long e = i + 4; i < n4 && i < e; i++) ((unsigned*)out)[i] = addq4(((const unsigned*)xa)[i], ((const unsigned*)xb)[i], q);
   }
-}
-
-__device__ __forceinline__ unsigned max4_s8(unsigned a, unsigned b) {
-  unsigned r = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    int x = (int)(int8_t)(a >> (8 * j)), y = (int)(int8_t)(b >> (8 * j));
-    r |= (unsigned)(max(x, y) & 255) << (8 * j);
-  }
-  return r;
 }
 
 __global__ __launch_bounds__(256) void maxpool_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ out, long total,
