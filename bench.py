@@ -12,15 +12,20 @@ VelocityTracker on the device, then (N > 1) one RCCL all-gather of the per-clip 
    data-path collective -> "weak" scaling; the only exchange is the final result gather.)
 
 Prints ONE JSON line on rank 0.  Which number is which:
-  value                 the contract: W warm-up steps, then exactly K steps + clip close between two fences, frames resident
-                        in HBM (what the task's bench contract defines as `value`).
+  value                 the contract and nothing else: W warm-up steps, then exactly K steps + clip close between two fences,
+                        frames resident in HBM (what the task's bench contract defines as `value`).  No other GPU work precedes
+                        the W warm-up steps in this process.
+  value_settled         (N = 1) the same W + K run repeated after `--settle-steps` detector-only steps: the GPU's clocks have
+                        settled; informational.
   value_h2d_inclusive   SURVEY.md 8d's metric, measured with the SAME W and K in the same process: uint8 frames in pinned
                         host memory -> H2D -> detect + NMS + track -> clip close -> every DataFrame row back in pinned host
                         memory, all inside its timed region.
-  cold_start            the contract run repeated in a FRESH process that starts before this one touches the GPU, without
-                        the clock-settle phase: what the first GPU process on an idle MI355X measures.
-  configs               BASELINE.json's other configurations (batch 1, batch 8, one clip time-batched, the 34-clip corpus on
-                        one GPU, Lite2 448x448), each with its SURVEY 8d roofline fraction.
+  configs               N = 1: BASELINE.json's other configurations (batch 1, batch 8, one clip time-batched, the 34-clip
+                        corpus on one GPU, Lite2 448x448), each with its SURVEY 8d roofline fraction.
+                        N > 1: BASELINE config 5 as written - the 34-clip corpus LPT-sharded over the ranks, one all-gather of
+                        the result records (corpus_sharded) - and SURVEY 8e's frame-major mode of ONE long clip: every rank
+                        detects a contiguous frame chunk, one all-gather of the 504-byte per-frame detection records, rank 0
+                        tracks (one_clip_frame_major).
   roofline              dominant kernel family, timed as ONE HIP-event bracket around all of its launches (the way
                         rocprofv3 --kernel-trace sees them; profiles/), with the PMC traffic of the same plan beside it.
   cpu_baseline          the CPU oracle (a port: the reference's TFLite path cannot run here) on a bounded sample.
@@ -33,14 +38,19 @@ import os
 import subprocess
 import sys
 import time
+import zlib
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # before torch initialises HIP (see vbt_amd/__init__.py)
+# a pipeline whose busy streams share a hardware queue loses a third of its throughput: here that is an error, not a warning
+# (vbt_amd/track.py: _place_streams; the contract run falls back to the warning and says so in `stream_placement`)
+os.environ.setdefault("VBT_STRICT_PLACEMENT", "1")
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_I8_PEAK = 5.0e15      # op/s dense: int8 MFMA = 2x the bf16 rate per clock (same guide, matrix-core table: ~2.5 PF bf16 dense)
 # Kernel plans tuned on an MI355X are pinned (profiles/plan_<model>.b<batch>.f0) so that every run and the committed
 # rocprofv3 / PMC summaries under profiles/ execute the same kernels; a missing file re-tunes on the spot.
 PLAN_LITE0 = os.path.join(ROOT, "profiles", "plan_lite0")
@@ -204,16 +214,18 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive pass, the splits and the other configurations")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's other configurations (b1, b8, clip1, corpus, Lite2)")
-    ap.add_argument("--no-cold-start", action="store_true", help="do not run the contract once more in a fresh process without the settle phase")
+    ap.add_argument("--cold-start", action="store_true", help="also run the contract once more in a fresh process started before this one touches the GPU")
     ap.add_argument("--contract-only", action="store_true", help="the timed region and nothing else (what the cold-start child runs)")
     ap.add_argument("--settle-steps", type=int, default=200,
-                    help="detector-only steps run before the warm-up so that the GPU is at steady clocks when the contract's W warm-up steps "
-                         "start (0 = off; reported as settle_steps; the same run WITHOUT it is reported as cold_start)")
+                    help="N = 1: detector-only steps run before the REPEAT of the contract run that is reported as value_settled (0 = no repeat); "
+                         "`value` itself is never preceded by them")
     ap.add_argument("--seed-offset", type=int, default=0, help="rehearsal: run this rank on the clips another rank would own")
     args = ap.parse_args()
     if args.contract_only:
-        args.no_extras = args.no_roofline = args.no_cold_start = True
+        args.no_extras = args.no_roofline = True
+        args.cold_start = False
         args.cpu_frames = 0
+        args.settle_steps = 0
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args.gpus)
@@ -221,7 +233,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     cold = None
-    if world == 1 and not args.no_cold_start and args.settle_steps > 0:
+    if world == 1 and args.cold_start:
         cold = cold_start_child(args)                       # before this process initialises HIP
     import torch
     args.gpus = world
@@ -262,7 +274,15 @@ def main():
     size = int(Container(MODEL).header["image_size"])
     frames_np = make_frames(seeds, 0, U, size)
     frames = torch.from_numpy(frames_np).to(dev)                      # resident in HBM before timing
-    pipe = Pipeline(MODEL, n, max_frames=max(K, STEADY_STEPS) + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
+    placement = "every busy stream on its own hardware queue"
+    try:
+        pipe = Pipeline(MODEL, n, max_frames=max(K, STEADY_STEPS) + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
+    except Exception as e:
+        if type(e).__name__ != "StreamPlacementError":
+            raise
+        os.environ["VBT_STRICT_PLACEMENT"] = "0"              # measure anyway, and say so
+        placement = "FAILED: busy streams share a hardware queue (profiler attached, or GPU_MAX_HW_QUEUES too small)"
+        pipe = Pipeline(MODEL, n, max_frames=max(K, STEADY_STEPS) + W + 8, fps=60.0, detection_treshold=0.5, device=local_rank, rows_per_frame=8)
     stream = torch.cuda.current_stream().cuda_stream
     fbytes = frames[0].numel()
     PH = 32                                                           # phases kept in the fixed-size result record
@@ -278,29 +298,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.settle_steps > 0:   # clock settle, not part of the contract's warm-up: no tracker state is touched
-        run_steps(args.settle_steps, 0, track=False)
-        torch.cuda.synchronize()
-        pipe.reset()
-    run_steps(W, 0)
-    fence()
-    t0 = time.perf_counter()
-    run_steps(K, W)
-    t_enq = time.perf_counter()
-    # clip close inside the timed region: pipeline drain, export-id selection + rep analysis on the device, ONE packed D2H
-    best, rows_n, nph, ovf, ph = pipe.close(cap=PH)
-    t_close = time.perf_counter()
-    # result record per clip: [best_id, n_rows, n_phases, PH x (t0,t1,y0,y1,rom,type)]
-    rec = np.zeros((n, 3 + PH * 6), np.float64)
+    def contract_run():
+        """W warm-up steps, fence, exactly K steps + clip close (+ the N > 1 gather), fence."""
+        run_steps(W, 0)
+        fence()
+        t0 = time.perf_counter()
+        run_steps(K, W)
+        t_enq = time.perf_counter()
+        # clip close inside the timed region: pipeline drain, export-id selection + rep analysis on the device, ONE packed D2H
+        best, rows_n, nph, ovf, ph = pipe.close(cap=PH)
+        t_close = time.perf_counter()
+        # result record per clip: [best_id, n_rows, n_phases, PH x (t0,t1,y0,y1,rom,type)]
+        rec = np.zeros((n, 3 + PH * 6), np.float64)
+        rec[:, 0], rec[:, 1], rec[:, 2] = best, rows_n, nph
+        rec[:, 3:] = ph.reshape(n, -1)
+        if dist is not None:                                             # the one exchange of the path: RCCL all-gather
+            rec_all = gather_records(dist, rec, world, cdev)
+        else:
+            rec_all = rec[None]
+        fence()
+        return time.perf_counter() - t0, t0, t_enq, t_close, rows_n, ovf, rec_all
+
+    dt_local, t0, t_enq, t_close, rows_n, ovf, rec_all = contract_run()      # `value`: nothing ran on the GPU before its warm-up steps
     nrows = int(rows_n.sum())
-    rec[:, 0], rec[:, 1], rec[:, 2] = best, rows_n, nph
-    rec[:, 3:] = ph.reshape(n, -1)
-    if dist is not None:                                             # the one exchange of the path: RCCL all-gather
-        rec_all = gather_records(dist, rec, world, cdev)
-    else:
-        rec_all = rec[None]
-    fence()
-    dt_local = time.perf_counter() - t0
     dt = dt_local
     if trace:
         print(f"[trace] rank {rank}: enqueue {1e3 * (t_enq - t0):.2f} ms, close {1e3 * (t_close - t_enq):.2f} ms, gather+fence "
@@ -315,8 +335,19 @@ def main():
     overflow = int((ovf != 0).sum())
 
     extras = {}
+    if world == 1 and args.settle_steps > 0 and not args.contract_only:
+        # the same run once more with the clocks settled (informational; ADVICE r03: the headline is the run above)
+        pipe.reset()
+        run_steps(args.settle_steps, 0, track=False)
+        torch.cuda.synchronize()
+        pipe.reset()
+        dts = contract_run()[0]
+        extras["value_settled"] = K * n / dts
+        extras["settled"] = {"frames_per_s": K * n / dts, "ms_per_step": dts / K * 1e3, "settle_steps": int(args.settle_steps),
+                             "note": "the contract run repeated in the same process after settle_steps detector-only steps"}
+        pipe.reset()
     if rank == 0 and world == 1 and not args.no_extras:
-        extras = extra_measurements(torch, pipe, frames, frames_np, n, K, W, U, fbytes, stream, PH)
+        extras.update(extra_measurements(torch, pipe, frames, frames_np, n, K, W, U, fbytes, stream, PH))
     roofline = None
     if rank == 0 and not args.no_roofline:
         roofline = roofline_block(pipe, n, stream)
@@ -325,6 +356,8 @@ def main():
     configs = None
     if rank == 0 and world == 1 and not args.no_extras and not args.no_configs:
         configs = other_configs(torch, dev)
+    if world > 1 and not args.no_configs:                    # every rank takes part: these are the sharded configurations
+        configs = multi_gpu_configs(torch, dist, dev, cdev, rank, world, local_rank)
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline(args.cpu_frames)
@@ -345,13 +378,13 @@ def main():
                        "clips_per_gpu": n, "batch": n, "frames_per_clip": K, "model_file": os.path.basename(MODEL),
                        "weights": "seeded synthetic (PCG64), post-training int8 quantised", "parallelism": f"clip-sharded x{world}",
                        "pipeline_depth": int(os.environ.get("VBT_PIPELINE_DEPTH", "3"))},
-            "value_is": "frames resident in HBM, after the clock-settle phase (settle_steps detector-only steps before the W warm-up steps); "
-                        "cold_start = the same run without it in a fresh process; value_h2d_inclusive = SURVEY 8d's host-to-host metric, same W and K",
+            "value_is": "the contract run and nothing before it: W warm-up steps, K timed steps + clip close, frames resident in HBM; value_settled = "
+                        "the same run repeated after a clock-settle phase; value_h2d_inclusive = SURVEY 8d's host-to-host metric, same W and K",
             "roofline_frac_8d": roofline_frac_8d(total_frames / dt / world, 0, n),
             "rows_emitted_rank0": int(nrows), "tracker_overflow_rank0": int(overflow),
             "clips_with_result": int((rec_all[..., 1] > 0).sum()),
             "timed_region_ms": {"enqueue": 1e3 * (t_enq - t0), "clip_close": 1e3 * (t_close - t_enq), "total": 1e3 * dt},
-            "settle_steps": int(args.settle_steps), "cold_start": cold,
+            "cold_start": cold, "stream_placement": placement,
             "rccl_ranks": rccl_ranks, "per_rank_frames_per_s": per_rank,
             "roofline": roofline, "cpu_baseline": cpu, "configs": configs,
         }
@@ -490,6 +523,26 @@ def other_configs(torch, dev):
     guarded("b1", lambda: small_batch(1, 2048))
     guarded("b8", lambda: small_batch(8, 1024))
 
+    # ---- INTEGRATION.md option A: the reference's loop UNCHANGED (track.py:159-234) over the drop-in objects: one host frame at a time
+    #      through Interpreter (run_odt: resize, H2D, batch-1 forward, D2H) and OCSort.update / tracker.trackers (one stream-ordered
+    #      read-back per frame) ----
+    def dropin():
+        from vbt_amd.interpreter import Interpreter
+        from vbt_amd.track import track
+        T = 400
+        bg = synth.background(0)
+        frames = [synth.render(bg, t) for t in range(T)]
+        it = Interpreter(MODEL, max_batch=1)
+        res = {}
+
+        def body():
+            res["rows"] = len(track(frames, it, detection_treshold=0.5, fps=60.0)["id"])
+        dt = _timed(torch, body)
+        return {"frames_per_s": T / dt, "ms_per_frame": dt / T * 1e3, "frames": T, "rows": res["rows"],
+                "note": "vbt_amd.track.track(): the per-frame loop of reference track.py:159-234 with Interpreter / run_odt / OCSort swapped in "
+                        "(INTEGRATION.md option A); every frame starts in host memory and every call returns host results, as in the reference"}
+    guarded("dropin_per_frame", dropin)
+
     # ---- config 2's clip on the time-batched path: ONE clip of 4096 frames, 64 consecutive frames per detector batch ----
     def clip1():
         T, F, U = 4096, 64, 256
@@ -622,6 +675,170 @@ def other_configs(torch, dev):
     return out
 
 
+def multi_gpu_configs(torch, dist, dev, cdev, rank, world, local_rank):
+    """N > 1 (every rank calls this): BASELINE config 5 as written and SURVEY 8e's frame-major mode, each one timed region between
+    two barriers with its one collective inside; rank 0 returns the dict that goes into the line."""
+    out = {}
+    for name, fn in (("corpus_sharded", corpus_sharded), ("one_clip_frame_major", one_clip_frame_major)):
+        try:
+            res = fn(torch, dist, dev, cdev, rank, world, local_rank)
+        except Exception as e:                                # a rank that fails here would hang the others at the next collective: leave
+            print(f"[bench] rank {rank}: {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            raise
+        if rank == 0:
+            out[name] = res
+        gc.collect()
+    return out if rank == 0 else None
+
+
+def corpus_sharded(torch, dist, dev, cdev, rank, world, local_rank, slots=64, U=8, PH=32):
+    """BASELINE config 5 (reference track.py:85-126 runs the clips one after the other): the 34-clip corpus - a synthetic stand-in with
+    the REAL per-clip frame counts and frame rates of dfs_ocsort (tests/golden/corpus_meta.json) - clip-sharded over the ranks by
+    longest-processing-time packing and run TIME-BATCHED on every rank (shard.run_schedule deals the 64 detector slots of a step to
+    the rank's clips in proportion to the frames they have left; OC-SORT walks a clip's run inside one launch); one all-gather of the
+    fixed-size per-clip result records at the end."""
+    from vbt_amd import shard, synth
+    from vbt_amd.track import Pipeline
+    clips = {k: (int(v[0]), float(v[1])) for k, v in json.load(open(CORPUS_META)).items()}
+    shards = shard.shard_clips({k: v[0] for k, v in clips.items()}, world)
+    mine = shards[rank]
+    n = len(mine)
+    lengths = np.array([clips[k][0] for k in mine])
+    fps = np.array([clips[k][1] for k in mine])
+    base = np.stack([np.stack([synth.render(synth.background(int(k), 320), 11 * u) for u in range(U)]) for k in mine])
+    frames = torch.from_numpy(np.concatenate([base] * (2 + slots // U), axis=1)).to(dev)      # [clip][cycle]: any run of <= 64 frames is contiguous
+    steps = shard.run_schedule(lengths, slots)
+    pipe = Pipeline(MODEL, slots, max_frames=int(lengths.max()), fps=fps, detection_treshold=0.5, tracker_clips=n, device=local_rank)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for rep in range(2):                                             # the first pass warms plans, pinned buffers and clocks
+        pipe.reset()
+        fence()
+        t0 = time.perf_counter()
+        for step in steps:
+            pipe.step_runs([frames[c, (f0 - 1) % U:(f0 - 1) % U + nf] for c, _, nf, f0 in step], step)
+        best, rows, nph, ovf, ph = pipe.close(cap=512)                # (the synthetic detector's noisy tracks give up to ~200 short phases)
+        ph = ph[:, :PH]                                               # the fixed-size record keeps the first PH
+        rec = np.zeros((n, 4 + PH * 6), np.float64)
+        rec[:, 0] = [int(k) for k in mine]
+        rec[:, 1], rec[:, 2], rec[:, 3] = best, rows, nph
+        rec[:, 4:] = ph.reshape(n, -1)
+        allrec = shard.gather_records(torch.from_numpy(rec).to(cdev), dist, pad_to=max(len(sh) for sh in shards)) if dist is not None else rec
+        fence()
+        dt = time.perf_counter() - t0
+    per_rank = None
+    if dist is not None:
+        tall = torch.zeros(world, dtype=torch.float64, device=cdev)
+        tall[rank] = dt
+        dist.all_reduce(tall)
+        per_rank = [float(t) for t in tall.tolist()]
+        dt = max(per_rank)
+    total = sum(v[0] for v in clips.values())
+    del pipe
+    return {"frames_per_s": total / dt, "seconds": dt, "clips": int(len(allrec)), "frames": total, "n_gpus": world, "per_rank_seconds": per_rank,
+            "rank0": {"clips": n, "frames": int(lengths.sum()), "steps": len(steps), "longest_run": max(nf for st in steps for _, _, nf, _ in st),
+                      "rows": int(rows.sum()), "overflow": int((ovf != 0).sum())},
+            "note": "34 synthetic clips with the reference corpus' frame counts (699...3243) and frame rates, LPT-sharded over the ranks, "
+                    "time-batched per rank, one all-gather of the per-clip result records inside the timed region"}
+
+
+def one_clip_frame_major(torch, dist, dev, cdev, rank, world, local_rank, T=4096, F=64, U=256):
+    """SURVEY 8e's second mode / the north_star's "gather of per-frame boxes": ONE long clip (config 2's 4096 frames).  The detector has no
+    state, so rank r detects the contiguous frame chunk r (64 frames per forward); ONE all-gather of the fixed-size per-frame records
+    (25 x (4 box + 1 score) f32 + count = 504 bytes per frame); the tracker is sequential per clip, so rank 0 alone walks all frames
+    (on the device, straight from the gathered records) and closes the clip.  Timed: barrier .. detect .. gather .. track + close +
+    rows on the host (rank 0) .. barrier."""
+    from vbt_amd import _lib, shard, synth
+    from vbt_amd.ocsort import MultiClipTracker
+    from vbt_amd.track import Pipeline
+    L = _lib.lib()
+    chunks = shard.frame_chunks(T, world)
+    s0, s1 = chunks[rank]
+    nmine = s1 - s0
+    per = max(e - b_ for b_, e in chunks)
+    bg = synth.background(0)
+    base = np.stack([synth.render(bg, t) for t in range(U)])
+    fr = torch.from_numpy(np.concatenate([base, base[:F]])).to(dev)          # a cycle of U frames: every run of F is contiguous
+    pipe = Pipeline(MODEL, F, max_frames=8, fps=60.0, tracker_clips=1, device=local_rank)
+    boxes = torch.zeros((per, 25, 4), dtype=torch.float32, device=dev)
+    scores = torch.zeros((per, 25), dtype=torch.float32, device=dev)
+    classes = torch.zeros((per, 25), dtype=torch.float32, device=dev)
+    counts = torch.zeros((per,), dtype=torch.int32, device=dev)
+    trk = MultiClipTracker(1, 8 * T + 75, max_age=30, asso_func="diou", iou_threshold=0.1, device=local_rank) if rank == 0 else None
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for rep in range(2):
+        if trk is not None:
+            trk.reset()
+        fence()
+        t0 = time.perf_counter()
+        for f0 in range(s0, s1, F):
+            nf = min(F, s1 - f0)
+            o = f0 - s0
+            s = f0 % U
+            pipe.step_runs(fr[s:s + nf], [(0, 0, nf, f0 + 1)], track=False,
+                           outputs=(boxes[o:o + nf], scores[o:o + nf], classes[o:o + nf], counts[o:o + nf]))
+        pipe.join_detectors()
+        rec = torch.cat([boxes.reshape(per, 100), scores, counts.to(torch.float32)[:, None]], dim=1)     # [per, 126] f32 = 504 B per frame
+        if dist is not None:
+            block = rec.to(cdev)
+            allrec = torch.empty((world * per, shard.RECORD_FLOATS), dtype=torch.float32, device=cdev)
+            dist.all_gather_into_tensor(allrec, block)                # the one exchange of this mode
+            allrec = allrec.to(dev)
+        else:
+            allrec = rec
+        if rank == 0:
+            gb = allrec[:, :100].contiguous()
+            gs = allrec[:, 100:125].contiguous()
+            gc_ = allrec[:, 125].to(torch.int32).contiguous()
+            for r_, (b_, e_) in enumerate(chunks):                    # one run per rank's chunk, in frame order (calls on a stream are ordered)
+                if e_ > b_:
+                    run = (_lib.Run * 1)(_lib.Run(0, r_ * per, 1, e_ - b_, b_ + 1, 1, 60.0))
+                    _lib.check(L.vbt_tracker_update_from_detections_seq(trk.handle, gb.data_ptr(), gs.data_ptr(), gc_.data_ptr(), world * per,
+                                                                        run, 1, 0.5, st))
+            trk.finish(0.45, stream=st)
+            best, rows_n, nph, ovf, ph = trk.summary(cap=512)
+            cnt_rows, rows = trk.rows_all(stream=st)
+            res.update(rows=int(rows_n.sum()), phases=int(nph.sum()), best_id=int(best[0]), checksum=zlib.crc32(rows[0, :cnt_rows[0]].tobytes()))
+        fence()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        tall = torch.zeros(world, dtype=torch.float64, device=cdev)
+        tall[rank] = dt
+        dist.all_reduce(tall)
+        dt = float(tall.max().item())
+    out = None
+    if rank == 0:
+        # the same clip on ONE rank's time-batched pipeline (outside the timed region): the rows must be the same rows
+        ref = Pipeline(MODEL, F, max_frames=T, fps=60.0, tracker_clips=1, device=local_rank)
+        for f0 in range(0, T, F):
+            s = f0 % U
+            ref.step_runs(fr[s:s + F], [(0, 0, F, f0 + 1)])
+        rb, rr, rn, ro, _ = ref.close(cap=512)
+        rc, rrows = ref.rows_all()
+        same = int(rr.sum()) == res["rows"] and int(rb[0]) == res["best_id"] and zlib.crc32(rrows[0, :rc[0]].tobytes()) == res["checksum"]
+        out = {"frames_per_s": T / dt, "seconds": dt, "frames": T, "n_gpus": world, "frames_per_rank": per, "record_bytes_per_frame": 4 * shard.RECORD_FLOATS,
+               "gather_bytes": 4 * shard.RECORD_FLOATS * per * world, "rows": res["rows"], "phases": res["phases"],
+               "rows_equal_single_gpu_time_batched": bool(same),
+               "note": "one 4096-frame clip: every rank detects a contiguous frame chunk (64 frames per forward), one all-gather of the 504-byte "
+                       "per-frame detection records, rank 0 walks all frames on the device and closes the clip; bound by rank 0's sequential walk"}
+        del ref
+    del pipe
+    return out
+
+
 def roofline_block(pipe, n, stream):
     """Dominant kernel family of the forward: all of its launches timed as ONE HIP-event bracket on the launch stream (one
     forward in flight, pipeline idle), i.e. without an event pair around every short launch; the committed rocprofv3
@@ -661,13 +878,27 @@ def roofline_block(pipe, n, stream):
                    "active_inst_frac": counters.get("active_inst_frac"),
                    "reading": "vector-ALU issue + waits between phases; neither the HBM nor the MFMA roof" if max(hbm_frac, mfma) < 0.5
                    else ("hbm" if hbm_frac >= mfma else "mfma")}
-    return {"bound": "hbm", "kernel": name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": traffic,
+    # which roof bounds the family: the roofline model's own rule - attainable = min(MFMA peak, arithmetic intensity x HBM peak) - on the
+    # family's algorithmic intensity (ops per algorithmic byte).  The int8 EfficientDet blocks sit far left of the ridge
+    # (625 op/B), so the memory roof is the binding one; `mfma` reports the other roof's figures beside it.
+    ops_per_launch = 2.0 * s.macs / s.launches
+    ai = ops_per_launch / (s.algorithmic_bytes / s.launches)
+    bound = "hbm" if ai * HBM_PEAK < MFMA_I8_PEAK else "mfma"
+    mfma_achieved = ops_per_launch / per_launch_s
+    mfma_blk = {"achieved": mfma_achieved / 1e12, "peak": MFMA_I8_PEAK / 1e12, "unit": "TOP/s", "frac": mfma_achieved / MFMA_I8_PEAK,
+                "arithmetic_intensity_op_per_byte": ai, "ridge_op_per_byte": MFMA_I8_PEAK / HBM_PEAK}
+    if bound == "mfma":
+        return {"bound": "mfma", "kernel": name, "achieved": mfma_blk["achieved"], "peak": mfma_blk["peak"], "unit": "TFLOP/s", "frac": mfma_blk["frac"],
+                "traffic": traffic, "hbm": {"achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK},
+                "launches_per_step": s.launches, "avg_launch_us": per_launch_s * 1e6, "limiter": limiter}
+    return {"bound": bound, "kernel": name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": traffic, "mfma": mfma_blk,
             "frac_traffic": (traffic / per_launch_s / HBM_PEAK) if traffic else None,
             "launches_per_step": s.launches, "avg_launch_us": per_launch_s * 1e6, "profiles_avg_launch_us": prof_us, "profiles_source": src,
             "algorithmic_bytes_per_launch": s.algorithmic_bytes / s.launches,
-            "bound_note": "`bound` names the SURVEY 8d roofline the fraction is taken against (HBM, algorithmic bytes of the unfused graph); "
-                          "`limiter` is what the PMC counters of this family say actually limits it",
+            "bound_note": "`bound` = the roof the roofline model says binds this family (algorithmic ops per algorithmic byte against the ridge "
+                          "MFMA peak / HBM peak); `frac` = algorithmic bytes per launch / launch time / HBM peak (SURVEY 8d); `limiter` is what the "
+                          "PMC counters of this family say actually limits it",
             "limiter": limiter,
             "families_ms_per_step": {stats[i].name.decode(): round(ms[i], 4) for i in range(cnt.value) if ms[i] > 0},
             "whole_net_algorithmic_GBps": sum(stats[i].algorithmic_bytes for i in range(cnt.value)) /

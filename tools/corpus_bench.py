@@ -12,21 +12,13 @@ import datetime
 import json
 import os
 import sys
-import time
-
-import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 os.environ.setdefault("VBT_PLAN_FILE", os.path.join(ROOT, "profiles", "plan_lite0"))
 import torch  # noqa: E402
-from vbt_amd import shard, synth  # noqa: E402
-from vbt_amd.track import Pipeline  # noqa: E402
-
-MODEL = os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm")
-META = os.path.join(ROOT, "tests", "golden", "corpus_meta.json")
-SLOTS, U, PH = 64, 8, 32
+import bench  # noqa: E402
 
 
 def main():
@@ -44,54 +36,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     cdev = dev if backend == "nccl" else torch.device("cpu")
-    clips = {k: (int(v[0]), float(v[1])) for k, v in json.load(open(META)).items()}
-    shards = shard.shard_clips({k: v[0] for k, v in clips.items()}, world)
-    mine = shards[rank]
-    n = len(mine)
-    lengths = np.array([clips[k][0] for k in mine])
-    fps = np.array([clips[k][1] for k in mine])
-    base = np.stack([np.stack([synth.render(synth.background(int(k), 320), 11 * u) for u in range(U)]) for k in mine])
-    frames = torch.from_numpy(np.concatenate([base] * (2 + SLOTS // U), axis=1)).to(dev)      # [clip][cycle]: any run of <= 64 frames is contiguous
-    steps = shard.run_schedule(lengths, SLOTS)
-    pipe = Pipeline(MODEL, SLOTS, max_frames=int(lengths.max()), fps=fps, detection_treshold=0.5, tracker_clips=n, device=local)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for rep in range(2):                                             # the first pass warms plans, pinned buffers and clocks
-        pipe.reset()
-        fence()
-        t0 = time.perf_counter()
-        for step in steps:
-            pipe.step_runs([frames[c, (f0 - 1) % U:(f0 - 1) % U + nf] for c, _, nf, f0 in step], step)
-        best, rows, nph, ovf, ph = pipe.close(cap=512)                # (the synthetic detector's noisy tracks give up to ~200 short phases)
-        ph = ph[:, :PH]                                               # the fixed-size record keeps the first PH
-        rec = np.zeros((n, 4 + PH * 6), np.float64)
-        rec[:, 0] = [int(k) for k in mine]
-        rec[:, 1], rec[:, 2], rec[:, 3] = best, rows, nph
-        rec[:, 4:] = ph.reshape(n, -1)
-        allrec = shard.gather_records(torch.from_numpy(rec).to(cdev), dist, pad_to=max(len(sh) for sh in shards)) if dist is not None else rec
-        fence()
-        dt = time.perf_counter() - t0
-    per_rank, rccl_ranks = None, None
-    if dist is not None:
-        tall = torch.zeros(world, dtype=torch.float64, device=cdev)
-        tall[rank] = dt
-        dist.all_reduce(tall)
-        per_rank = [float(t) for t in tall.tolist()]
-        dt = max(per_rank)
-        ones = torch.ones(1, dtype=torch.float64, device=cdev)
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+    res = bench.corpus_sharded(torch, dist, dev, cdev, rank, world, local)      # the body lives in bench.py (configs.corpus_sharded at N > 1)
     if rank == 0:
-        total = sum(v[0] for v in clips.values())
-        print(json.dumps({"config": "34-clip corpus, clip-sharded, time-batched", "n_gpus": world, "rccl_ranks": rccl_ranks, "clips": len(allrec),
-                          "frames": total, "seconds": round(dt, 4), "frames_per_s": round(total / dt), "per_rank_seconds": per_rank,
-                          "rank0": {"clips": n, "frames": int(lengths.sum()), "steps": len(steps), "longest_run": max(nf for s in steps for _, _, nf, _ in s),
-                                    "rows": int(rows.sum()), "overflow": int((ovf != 0).sum())}}))
+        print(json.dumps(dict(res, config="34-clip corpus, clip-sharded, time-batched")))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,6 +16,7 @@ python3 bench.py --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.e
 echo "bench k20 done"
 session() {   # $1 = output prefix ("" | lite2_), environment selects model and plan
   local PRE=$1
+  export VBT_STRICT_PLACEMENT=0   # under rocprofv3 the placement probe may read every pair of streams as serialised (exported: the program after `--` must be python3 itself)
   local B="bench.py --steps 50 --warmup 5 --cpu-frames 0 --no-extras --no-roofline --settle-steps 0"
   VBT_PIPELINE_DEPTH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${PRE}trace_d1 -o d1 -- python3 $B > /dev/null 2> $OUT/${PRE}trace_d1.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${PRE}trace_d3 -o d3 -- python3 $B > /dev/null 2> $OUT/${PRE}trace_d3.err

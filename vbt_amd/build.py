@@ -30,24 +30,22 @@ def _headers():
            [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include")) if f.endswith(".h")]
 
 
-# Kernel headers whose change cannot affect a translation unit's code (launchers.h shows every argument struct to every unit, but
-# a unit only instantiates the kernels of its own headers).  Anything not listed here is a dependency of every unit.
-KERNEL_HEADERS = {"op_kernels.h", "band_block.h", "expdw_block.h", "expdw2_block.h", "stem_block.h", "image_block.h", "fused_block.h"}
-UNIT_KERNEL_HEADERS = {
-    "k_band.hip": {"band_block.h", "expdw_block.h", "expdw2_block.h", "stem_block.h", "fused_block.h"},
-    "k_image.hip": {"image_block.h", "fused_block.h"},
-    "k_fused_mbconv.hip": {"fused_block.h"},
-    "k_fused_sepconv.hip": {"fused_block.h"},
-    "tracker.hip": set(),
-    "frames.hip": set(),
-}
+def _dep_file(obj):
+    return obj[:-2] + ".d"
 
 
-def _unit_headers(unit, hdrs):
-    mine = UNIT_KERNEL_HEADERS.get(unit)
-    if mine is None:            # the planner (detector.hip) and anything new: every header
-        return hdrs
-    return [h for h in hdrs if os.path.basename(h) not in KERNEL_HEADERS or os.path.basename(h) in mine]
+def _deps(obj, src):
+    """Prerequisites of an object as the compiler saw them (hipcc -MD -MF obj/x.d): the source and every header it pulled in,
+    directly or not.  No depfile yet (first build, or an object of an older build.py): every header of the tree."""
+    d = _dep_file(obj)
+    if not os.path.exists(d):
+        return [src] + _headers()
+    txt = open(d).read().replace("\\\n", " ")
+    deps = []
+    for rule in txt.split("\n"):
+        if ":" in rule:
+            deps += rule.split(":", 1)[1].split()
+    return [p for p in deps if p.startswith(os.path.dirname(HERE))] or [src] + _headers()     # (system headers: covered by the compiler version tag)
 
 
 def _stale(target, deps):
@@ -66,16 +64,19 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = _headers()
-    flag_tag = os.path.join(OBJ, "flags.txt")                    # objects built with other flags are stale too
-    flags_txt = " ".join(FLAGS)
+    flag_tag = os.path.join(OBJ, "flags.txt")                    # objects built with other flags or another compiler are stale too
+    try:
+        cc_version = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().replace("\n", " | ")
+    except OSError:
+        cc_version = "unknown"
+    flags_txt = " ".join(FLAGS) + "\n" + cc_version
     if not os.path.exists(flag_tag) or open(flag_tag).read() != flags_txt:
         force = True
     jobs = []
     for s in sources():
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
-        if force or _stale(obj, [src] + _unit_headers(s, hdrs)):
-            jobs.append([hipcc] + FLAGS + ["-c", "-o", obj, src])
+        if force or _stale(obj, _deps(obj, src)):
+            jobs.append([hipcc] + FLAGS + ["-MD", "-MF", _dep_file(obj), "-c", "-o", obj, src])
 
     def run(cmd):
         if verbose:

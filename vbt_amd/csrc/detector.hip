@@ -119,10 +119,12 @@ struct vbt_model {
   std::vector<size_t> telems;  // per-frame elements
   int8_t* arena = nullptr;
   uint8_t* frames_stage = nullptr;  // device staging for host frames
-  float* out_boxes = nullptr;       // device staging for host outputs
+  float* out_boxes = nullptr;       // device staging for host outputs: ONE block boxes | scores | classes | counts ...
   float* out_scores = nullptr;
   float* out_classes = nullptr;
   int* out_counts = nullptr;
+  unsigned char* out_host = nullptr;   // ... and its pinned host mirror: vbt_detect's results come back with one copy
+  size_t out_bytes = 0;
   float* d_anchors = nullptr;
   unsigned char* d_luts = nullptr;   // post-process tables (see PostArgs)
   std::vector<float> post_tables_host;   // scores indexed by rank byte + 128
@@ -2372,12 +2374,15 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
   for (size_t i = 0; i < m->tensors.size(); i++) m->tptr[i] = m->arena + off[i];
   size_t fbytes = (size_t)max_batch * m->hdr.image_size * m->hdr.image_size * 3;
   const int md = m->hdr.max_detections;
-  if (fenced_malloc(m, (void**)&m->frames_stage, fbytes + 64) != hipSuccess || hipMalloc((void**)&m->out_boxes, (size_t)max_batch * md * 16) != hipSuccess ||
-      hipMalloc((void**)&m->out_scores, (size_t)max_batch * md * 4) != hipSuccess || hipMalloc((void**)&m->out_classes, (size_t)max_batch * md * 4) != hipSuccess ||
-      hipMalloc((void**)&m->out_counts, (size_t)max_batch * 4) != hipSuccess) {
+  m->out_bytes = (size_t)max_batch * (md * 24 + 4);
+  if (fenced_malloc(m, (void**)&m->frames_stage, fbytes + 64) != hipSuccess || hipMalloc((void**)&m->out_boxes, m->out_bytes) != hipSuccess ||
+      hipHostMalloc((void**)&m->out_host, m->out_bytes, hipHostMallocDefault) != hipSuccess) {
     set_error("hipMalloc for staging buffers failed");
     return fail(VBT_ERR_HIP);
   }
+  m->out_scores = m->out_boxes + (size_t)max_batch * md * 4;
+  m->out_classes = m->out_scores + (size_t)max_batch * md;
+  m->out_counts = (int*)(m->out_classes + (size_t)max_batch * md);
   if ((rc = build_plan(m)) != VBT_OK) return fail(rc);
   for (const OpRec& op : m->ops)
     if (op.type == OP_POSTPROCESS) {
@@ -2481,8 +2486,8 @@ void vbt_model_destroy(vbt_model* m) {
   for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   for (void* p : m->owned) (void)hipFree(p);
-  (void)hipFree(m->out_boxes);  // arena and frames_stage are in `owned`
-  (void)hipFree(m->out_scores); (void)hipFree(m->out_classes); (void)hipFree(m->out_counts);
+  (void)hipFree(m->out_boxes);  // (one block: boxes | scores | classes | counts); arena and frames_stage are in `owned`
+  if (m->out_host) (void)hipHostFree(m->out_host);
   delete m;
 }
 
@@ -2524,12 +2529,17 @@ int vbt_detect(vbt_model* m, const uint8_t* frames, int B, int frames_on_device,
   int rc = forward(m, fd, B, st, db, ds, dc, dn);
   if (rc) return rc;
   if (!outputs_on_device) {
+    // one copy of the staging block into its pinned mirror, one synchronisation of this stream, then the caller's arrays are
+    // filled on the host (four copies into pageable memory used to be four staged transfers)
     const int md = m->hdr.max_detections;
-    VBT_HIP_CHECK(hipMemcpyAsync(boxes, db, (size_t)B * md * 16, hipMemcpyDeviceToHost, st));
-    VBT_HIP_CHECK(hipMemcpyAsync(scores, ds, (size_t)B * md * 4, hipMemcpyDeviceToHost, st));
-    VBT_HIP_CHECK(hipMemcpyAsync(classes, dc, (size_t)B * md * 4, hipMemcpyDeviceToHost, st));
-    VBT_HIP_CHECK(hipMemcpyAsync(counts, dn, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    const size_t mb = (size_t)m->max_batch;
+    VBT_HIP_CHECK(hipMemcpyAsync(m->out_host, m->out_boxes, m->out_bytes, hipMemcpyDeviceToHost, st));
     VBT_HIP_CHECK(hipStreamSynchronize(st));
+    const unsigned char* h = m->out_host;
+    memcpy(boxes, h, (size_t)B * md * 16);
+    memcpy(scores, h + mb * md * 16, (size_t)B * md * 4);
+    memcpy(classes, h + mb * md * 20, (size_t)B * md * 4);
+    memcpy(counts, h + mb * md * 24, (size_t)B * 4);
   }
   return VBT_OK;
 }

@@ -746,6 +746,41 @@ __global__ __launch_bounds__(64) void tracker_kernel(ClipState* states, Row* row
   }
 }
 
+// The reference's own call shape - tracker.update(dets, []) once per frame on ONE clip, then tracker.trackers[i].id / .kf.x
+// (track.py:186-199): the frame's detections and its time stamp travel in the kernel arguments (no allocation, no host-to-device
+// copy), and what the caller reads back afterwards - update()'s rows and every live tracker's id + kf.x - is packed into one small
+// block that comes back with ONE stream-ordered copy into pinned memory (the per-call path used to cost three hipMalloc, three
+// blocking copies and two device-wide synchronisations).
+struct OneFrameArg {
+  double det[MAXD][6];
+  double time;
+  int n;
+};
+constexpr int VIEW_DOUBLES = 2 + MAXD * 9 + MAXT * 8;   // last_n, ntrk | last_out[25][9] | per tracker: id, x[7]
+__global__ __launch_bounds__(64) void tracker_one_kernel(ClipState* states, Row* rows, int rows_cap, int clip, OneFrameArg a, TrackParams p,
+                                                         double q44, double q66, double* view) {
+  __shared__ StepShared sh;
+  const int lane = threadIdx.x;
+  ClipState& st = states[clip];
+  if (lane == 0) {  // dets = dets[confs > det_thresh]
+    int m = 0;
+    for (int i = 0; i < a.n && i < MAXD; i++)
+      if (a.det[i][4] > p.det_thresh) { for (int j = 0; j < 6; j++) sh.det[m][j] = a.det[i][j]; m++; }
+    sh.flag = m;
+  }
+  __syncthreads();
+  ocsort_step(st, rows + (size_t)clip * rows_cap, rows_cap, sh, sh.flag, a.time, p, q44, q66, lane);
+  __syncthreads();
+  if (lane == 0) { view[0] = (double)st.last_n; view[1] = (double)st.ntrk; }
+  for (int i = lane; i < MAXD * 9; i += 64) view[2 + i] = (&st.last_out[0][0])[i];
+  if (lane < st.ntrk) {
+    const Trk& k = st.trk[st.order[lane]];
+    double* o = view + 2 + MAXD * 9 + lane * 8;
+    o[0] = (double)k.id;
+    for (int j = 0; j < 7; j++) o[1 + j] = k.x[j];
+  }
+}
+
 // ... or straight from the detector's device outputs (fused pipeline): applies the detection
 // threshold of reference odt.py:70-75 and the reorder of odt.py:102-118.
 // slot = position in the detector batch; clip = tracker state it feeds (map == nullptr: the same index; a negative entry
@@ -1128,6 +1163,9 @@ struct vbt_tracker {
   unsigned char* d_summary = nullptr;    // packed close block (pack_summary_kernel), grown on demand
   unsigned char* h_summary = nullptr;    // its pinned host copy
   size_t summary_bytes = 0;
+  double* d_view = nullptr;              // packed read-back block of the one-frame path (tracker_one_kernel)
+  double* h_view = nullptr;              // its pinned host copy
+  int view_clip = -1;                    // clip whose state h_view mirrors (-1: none: the state changed on another path)
 };
 
 extern "C" {
@@ -1167,6 +1205,8 @@ int vbt_tracker_create(int n_clips, int rows_cap, const vbt_tracker_params* prm,
   t->summary_bytes = (16 + (size_t)MAXPH * 48) * n_clips;
   if (hipMalloc((void**)&t->d_summary, t->summary_bytes) != hipSuccess) return fail("summary");
   if (hipHostMalloc((void**)&t->h_summary, t->summary_bytes, hipHostMallocDefault) != hipSuccess) return fail("pinned summary");
+  if (hipMalloc((void**)&t->d_view, sizeof(double) * VIEW_DOUBLES) != hipSuccess) return fail("view");
+  if (hipHostMalloc((void**)&t->h_view, sizeof(double) * VIEW_DOUBLES, hipHostMallocDefault) != hipSuccess) return fail("pinned view");
   init_states_kernel<<<(n_clips + 63) / 64, 64>>>(t->states, n_clips);
   VBT_HIP_CHECK(hipDeviceSynchronize());
   *out = t;
@@ -1179,6 +1219,8 @@ void vbt_tracker_destroy(vbt_tracker* t) {
   (void)hipFree(t->phases); (void)hipFree(t->nph); (void)hipFree(t->T); (void)hipFree(t->best);
   if (t->d_summary) (void)hipFree(t->d_summary);
   if (t->h_summary) (void)hipHostFree(t->h_summary);
+  if (t->d_view) (void)hipFree(t->d_view);
+  if (t->h_view) (void)hipHostFree(t->h_view);
   delete t;
 }
 
@@ -1187,12 +1229,28 @@ int vbt_tracker_reset(vbt_tracker* t) {
   init_states_kernel<<<(t->n_clips + 63) / 64, 64>>>(t->states, t->n_clips);
   VBT_HIP_CHECK(hipDeviceSynchronize());
   t->finished = false;
+  t->view_clip = -1;
   return VBT_OK;
 }
 
 int vbt_tracker_update(vbt_tracker* t, const double* dets, const int32_t* counts, const double* times, int F) {
   if (!t || !dets || !counts || !times || F < 1) { set_error("vbt_tracker_update: bad argument"); return VBT_ERR_ARG; }
   VBT_HIP_CHECK(hipSetDevice(t->device));
+  t->view_clip = -1;
+  if (F == 1 && t->n_clips == 1) {   // OCSort.update(dets, []) of the reference's loop: everything in the kernel arguments
+    if (counts[0] <= 0) return VBT_OK;   // (track.py:180-181: the tracker is not stepped on empty frames)
+    OneFrameArg a;
+    a.n = std::min((int)counts[0], MAXD);
+    a.time = times[0];
+    memcpy(a.det, dets, sizeof(double) * 6 * a.n);
+    tracker_one_kernel<<<1, 64, 0, nullptr>>>(t->states, t->rows, t->rows_cap, 0, a, t->p, t->q44, t->q66, t->d_view);
+    VBT_HIP_CHECK(hipGetLastError());
+    VBT_HIP_CHECK(hipMemcpyAsync(t->h_view, t->d_view, sizeof(double) * VIEW_DOUBLES, hipMemcpyDeviceToHost, nullptr));
+    VBT_HIP_CHECK(hipStreamSynchronize(nullptr));
+    t->view_clip = 0;
+    t->finished = false;
+    return VBT_OK;
+  }
   size_t nd = (size_t)F * t->n_clips;
   double* dd = nullptr; int* dc = nullptr; double* dt = nullptr;
   VBT_HIP_CHECK(hipMalloc((void**)&dd, nd * MAXD * 6 * sizeof(double)));
@@ -1225,6 +1283,7 @@ static int launch_steps(vbt_tracker* t, const float* boxes_dev, const float* sco
   }
   VBT_HIP_CHECK(hipGetLastError());
   t->finished = false;
+  t->view_clip = -1;
   return VBT_OK;
 }
 
@@ -1273,6 +1332,7 @@ int vbt_tracker_update_from_detections_seq(vbt_tracker* t, const float* boxes_de
     if ((long long)r.frame0 + (long long)(r.n_frames - 1) * r.frame_step > 0x7fffffffLL) { set_error("run %d: frame number overflow", i); return VBT_ERR_ARG; }
   }
   hipStream_t st = (hipStream_t)stream;
+  VBT_HIP_CHECK(hipSetDevice(t->device));     // (the LDS opt-in below is a per-device function attribute)
   for (int r0 = 0; r0 < n_runs; r0 += META_RUNS) {
     const int nb = std::min(META_RUNS, n_runs - r0);
     SeqMeta meta;
@@ -1283,19 +1343,22 @@ int vbt_tracker_update_from_detections_seq(vbt_tracker* t, const float* boxes_de
     int longest = 0;
     for (int i = 0; i < nb; i++) longest = std::max(longest, meta.run[i].clip >= 0 ? meta.run[i].n_frames : 0);
     static const bool lds_off = getenv("VBT_SEQ_NO_LDS") != nullptr;
-    const int lds_state = (longest >= SEQ_LDS_MIN && !lds_off) ? 1 : 0;
+    int lds_state = (longest >= SEQ_LDS_MIN && !lds_off) ? 1 : 0;
     if (lds_state) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tracker_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ClipState));
-        attr_set = true;
-      }
+      // opt in to the dynamic LDS of the cached state once per device; if the runtime refuses, the walk works on global memory
+      static int attr_state[64] = {0};   // per device: 0 = not tried, 1 = granted, -1 = refused
+      const int di = t->device < 64 ? t->device : 63;
+      if (attr_state[di] == 0)
+        attr_state[di] = hipFuncSetAttribute(reinterpret_cast<const void*>(&tracker_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)sizeof(ClipState)) == hipSuccess ? 1 : -1;
+      if (attr_state[di] < 0) lds_state = 0;
     }
     tracker_seq_kernel<<<nb, 64, lds_state ? sizeof(ClipState) : 0, st>>>(t->states, t->rows, t->rows_cap, boxes_dev, scores_dev, counts_dev, meta,
                                                                            det_threshold, t->p, t->q44, t->q66, lds_state);
   }
   VBT_HIP_CHECK(hipGetLastError());
   t->finished = false;
+  t->view_clip = -1;
   return VBT_OK;
 }
 
@@ -1319,6 +1382,17 @@ static int fetch_state_header(vbt_tracker* t, int clip, ClipState* hdr_only) {
 
 int vbt_tracker_last_output(vbt_tracker* t, int clip, double* out7, double* vel2, int cap, int* M) {
   if (!t || !out7 || !vel2 || !M || clip < 0 || clip >= t->n_clips) { set_error("bad argument"); return VBT_ERR_ARG; }
+  if (t->view_clip == clip) {   // the one-frame path brought it back already
+    const int n = std::min((int)t->h_view[0], cap);
+    for (int i = 0; i < n; i++) {
+      const double* lo = t->h_view + 2 + i * 9;
+      for (int j = 0; j < 7; j++) out7[i * 7 + j] = lo[j];
+      vel2[i * 2] = lo[7];
+      vel2[i * 2 + 1] = lo[8];
+    }
+    *M = n;
+    return VBT_OK;
+  }
   VBT_HIP_CHECK(hipDeviceSynchronize());
   std::vector<char> buf(offsetof(ClipState, trk));
   VBT_HIP_CHECK(hipMemcpy(buf.data(), &t->states[clip], buf.size(), hipMemcpyDeviceToHost));
@@ -1351,6 +1425,16 @@ int vbt_tracker_status(vbt_tracker* t, int clip, int32_t* n_rows, int32_t* n_tra
 
 int vbt_tracker_get_trackers(vbt_tracker* t, int clip, int32_t* ids, double* kfx, int cap, int* n) {
   if (!t || !ids || !kfx || !n || clip < 0 || clip >= t->n_clips) { set_error("bad argument"); return VBT_ERR_ARG; }
+  if (t->view_clip == clip) {
+    const int m = std::min((int)t->h_view[1], cap);
+    for (int i = 0; i < m; i++) {
+      const double* o = t->h_view + 2 + MAXD * 9 + i * 8;
+      ids[i] = (int32_t)o[0];
+      for (int j = 0; j < 7; j++) kfx[i * 7 + j] = o[1 + j];
+    }
+    *n = m;
+    return VBT_OK;
+  }
   VBT_HIP_CHECK(hipDeviceSynchronize());
   std::vector<char> buf(sizeof(ClipState));
   VBT_HIP_CHECK(hipMemcpy(buf.data(), &t->states[clip], sizeof(ClipState), hipMemcpyDeviceToHost));

@@ -105,7 +105,13 @@ def export_dataframe(data, src_name, model_path, df_dir=None, write=True):
     return df, int(max_distance_id), df_path
 
 
-_STREAMS = {}   # device -> {"streams": [torch.cuda.ExternalStream], "free": [indices]}: see Pipeline._new_stream
+# device -> {"streams": [torch.cuda.ExternalStream], "free": [indices], "group": {index: hardware-queue group}, "reps": [one
+# stream index per known group]}: the process-wide stream pool of every Pipeline (see Pipeline._new_stream / _place_streams)
+_STREAMS = {}
+
+
+class StreamPlacementError(RuntimeError):
+    pass
 
 
 class Pipeline:
@@ -193,68 +199,121 @@ class Pipeline:
             for S in self._det_streams:
                 S.synchronize()
 
+    def _pool(self):
+        return _STREAMS.setdefault(self._dev, {"streams": [], "free": [], "group": {}, "reps": []})
+
+    def _take(self, tdev, i=None, create=False):
+        """Stream i of the pool (None: the lowest free index, or - none free / create - a new stream), now owned by this pipeline."""
+        pool = self._pool()
+        if i is None:
+            if pool["free"] and not create:
+                i = min(pool["free"])
+            else:
+                h = ctypes.c_void_p()
+                _lib.check(_lib.lib().vbt_stream_create(self._dev, ctypes.byref(h)))
+                pool["streams"].append(self._torch.cuda.ExternalStream(h.value, device=tdev))
+                i = len(pool["streams"]) - 1
+                pool["free"].append(i)
+        pool["free"].remove(i)
+        self._own_streams.append(i)
+        return i
+
     def _new_stream(self, tdev):
         torch = self._torch
         if os.environ.get("VBT_TORCH_POOL_STREAMS") == "1":
             return torch.cuda.Stream(device=tdev)
-        # Streams are kept for the life of the process and handed out again when a pipeline goes away (lowest index first, so
-        # a pipeline's streams stay neighbours in creation order = on distinct hardware queues).  They are never destroyed:
-        # torch's caching allocator may still hold record_stream() references to them.
-        pool = _STREAMS.setdefault(self._dev, {"streams": [], "free": []})
-        if pool["free"]:
-            i = min(pool["free"])
-            pool["free"].remove(i)
-        else:
-            import ctypes
-            h = ctypes.c_void_p()
-            _lib.check(_lib.lib().vbt_stream_create(self._dev, ctypes.byref(h)))
-            pool["streams"].append(torch.cuda.ExternalStream(h.value, device=tdev))
-            i = len(pool["streams"]) - 1
-        self._own_streams.append(i)
-        return pool["streams"][i]
+        # Streams are kept for the life of the process and handed out again when a pipeline goes away.  They are never
+        # destroyed: torch's caching allocator may still hold record_stream() references to them.
+        return self._pool()["streams"][self._take(tdev)]
 
     def _place_streams(self, tdev):
         """The streams that carry kernels side by side (detector slots, the copy stream, the tracker stream unless its step
-        runs inline) must sit on distinct hardware queues.  HIP deals queues to streams in a zig-zag over GPU_MAX_HW_QUEUES
-        that also counts streams created by others (with 6 queues two detector streams of a fresh process shared one:
-        72 k instead of 94 k frames/s), and a stream's queue cannot be queried - so every pair is timed with a spinning wave
-        (vbt_streams_share_queue, 3 ms in all) and a stream that collides is swapped for the next one of the pool."""
+        runs inline) must sit on distinct hardware queues.  HIP binds a stream to one of GPU_MAX_HW_QUEUES hardware queues when
+        it is created (a zig-zag that also counts streams created by others) and the queue cannot be queried, so a pool stream
+        is CLASSIFIED once per process: timed with a spinning wave against one representative of every queue group known so far
+        (vbt_streams_share_queue, ~0.3 ms per probe).  A pipeline then takes its busy streams from distinct groups - a stream that
+        once collided is simply left for another role - and only creates streams while some group is still unseen, so that
+        any number of pipelines created one after the other in a process end up on the same few streams (round 3: the twelve-
+        stream budget of the old swap loop ran out after a few pipelines and the pipeline silently shared queues: -35 %).
+        VBT_STRICT_PLACEMENT=1 turns a failed placement into StreamPlacementError (bench.py sets it)."""
         if os.environ.get("VBT_TORCH_POOL_STREAMS") == "1" or os.environ.get("VBT_PLACE_STREAMS", "1") == "0":
             return
-        import ctypes
         L = _lib.lib()
+        pool = self._pool()
         self._torch.cuda.synchronize()
 
-        def shared(a, b):
+        def shared(i, j):
             sh = ctypes.c_int()
+            a, b = pool["streams"][i], pool["streams"][j]
             for _ in range(2):      # host-timed: a descheduled host thread can make one probe read "shared"; two in a row cannot
                 _lib.check(L.vbt_streams_share_queue(a.cuda_stream, b.cuda_stream, 150, ctypes.byref(sh)))
                 if not sh.value:
                     return False
             return True
 
+        def group_of(i):
+            if i not in pool["group"]:
+                g = next((g for g, rep in enumerate(pool["reps"]) if shared(i, rep)), None)
+                if g is None:
+                    g = len(pool["reps"])
+                    pool["reps"].append(i)
+                pool["group"][i] = g
+            return pool["group"][i]
+
         # (four hardware queues: with four forwards in flight the copy stream has to share one, which costs a small batch nothing)
         busy = [("det", k) for k in range(self.depth)] + ([("copy", 0)] if self.depth < 4 else []) + ([] if self._trk_inline else [("trk", 0)])
-        placed, budget, warned = [], 12, False                # at most 12 replacement streams per pipeline
-        for kind, k in busy:
-            cur = self._det_streams[k] if kind == "det" else (self._copy_stream if kind == "copy" else self._trk_stream)
-            while any(shared(cur, p) for p in placed):
-                if budget == 0:
-                    if not warned:
-                        import warnings
-                        warnings.warn("vbt_amd: could not give every pipeline stream its own hardware queue (GPU_MAX_HW_QUEUES "
-                                      "too small, or kernels are being serialised by a profiler); throughput will be lower")
-                        warned = True
-                    break
-                budget -= 1
-                cur = self._new_stream(tdev)               # the colliding stream stays owned (out of the free list) until __del__
-            placed.append(cur)
-            if kind == "det":
-                self._det_streams[k] = cur
-            elif kind == "copy":
-                self._copy_stream = cur
-            else:
-                self._trk_stream = cur
+        index_of = {id(st): i for i, st in enumerate(pool["streams"])}
+        roles = {("det", k): index_of[id(self._det_streams[k])] for k in range(self.depth)}
+        roles[("copy", 0)] = index_of[id(self._copy_stream)]
+        roles[("trk", 0)] = index_of[id(self._trk_stream)]
+        nq = max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+        used, failed = set(), False
+        for role in busy:
+            cur = roles[role]
+            if group_of(cur) in used:
+                # another stream of a group this pipeline does not use yet: one it already holds for an idle role, a free pool
+                # stream, or - while fewer groups than hardware queues are known, and at most 3 nq times - a new one
+                spare = [i for r_, i in roles.items() if r_ not in busy and group_of(i) not in used]
+                cand = spare or [i for i in sorted(pool["free"]) if group_of(i) not in used]
+                created = 0
+                while not cand and len(pool["reps"]) < nq and created < 3 * nq:
+                    i = self._take(tdev, create=True)
+                    created += 1
+                    if group_of(i) not in used:
+                        cand = [i]
+                    else:
+                        pool["free"].append(i)          # stays in the pool for a later pipeline / another role
+                        self._own_streams.remove(i)
+                if not cand:
+                    failed = True
+                    continue
+                new = cand[0]
+                if new in pool["free"]:
+                    self._take(tdev, new)
+                if spare:                                # swap the two roles' streams
+                    other = next(r_ for r_, i in roles.items() if i == new)
+                    roles[other] = cur
+                roles[role] = new
+                cur = new
+            used.add(group_of(cur))
+        for k in range(self.depth):
+            self._det_streams[k] = pool["streams"][roles[("det", k)]]
+        self._copy_stream = pool["streams"][roles[("copy", 0)]]
+        self._trk_stream = pool["streams"][roles[("trk", 0)]]
+        # streams taken but left without a role go back to the pool
+        held = set(roles.values())
+        for i in [i for i in self._own_streams if i not in held]:
+            self._own_streams.remove(i)
+            pool["free"].append(i)
+        if failed:
+            msg = (f"vbt_amd: could not give every pipeline stream its own hardware queue: {len(busy)} busy streams (depth {self.depth}"
+                   f"{'' if self._trk_inline else ' + tracker stream'}{' + copy stream' if self.depth < 4 else ''}), {len(pool['reps'])} distinct "
+                   f"queues seen, GPU_MAX_HW_QUEUES={nq} (too few queues for this configuration, or kernels are being serialised by a "
+                   "profiler); throughput will be lower")
+            if os.environ.get("VBT_STRICT_PLACEMENT") == "1":
+                raise StreamPlacementError(msg)
+            import warnings
+            warnings.warn(msg)
 
     def __del__(self):
         try:
@@ -390,7 +449,7 @@ class Pipeline:
             self._stage[j] = torch.empty(tuple(shape), dtype=torch.uint8, device=torch.device(f"cuda:{self._dev}"))
         return self._stage[j]
 
-    def step_runs(self, frames, runs, stream=None, src_hw=None, swap_rb=False, track=True):
+    def step_runs(self, frames, runs, stream=None, src_hw=None, swap_rb=False, track=True, outputs=None):
         """Time-batched step (the reference's unit of work is ONE video, track.py:85-126,159-247): the detector batch holds
         RUNS of consecutive frames of a clip instead of one frame of each clip; the OC-SORT steps of a run are walked in
         frame order by one wavefront inside ONE tracker launch (vbt_tracker_update_from_detections_seq).
@@ -398,9 +457,14 @@ class Pipeline:
         is frame number frame0 + f * frame_step (1-based) of tracker clip `clip`; its time stamp is frame number / fps[clip].
         frames: the assembled batch - a device tensor / raw device pointer or a (pinned) host tensor [B,H,W,3], B = slots used
         - or a list with one tensor [n_frames,H,W,3] per run (device or host, contiguous): the batch is then assembled here,
-        by one gather launch (device sources) or one H2D copy per run on the copy stream (host sources)."""
+        by one gather launch (device sources) or one H2D copy per run on the copy stream (host sources).
+        outputs (with track=False): (boxes [B,25,4] f32, scores [B,25] f32, classes [B,25] f32, counts [B] i32) device tensors that
+        receive this step's detections instead of the pipeline's ring buffers - the frame-major multi-GPU mode
+        collects a whole frame chunk's detections for the gather; the caller keeps them alive until the stream has run."""
         torch = self._torch
         L = _lib.lib()
+        if outputs is not None and track:
+            raise ValueError("step_runs: outputs= is for detector-only steps (track=False)")
         k = self._step_idx % self.depth
         if k in self._pending:
             raise RuntimeError(f"Pipeline: ring slot {k} still holds a step whose tracker update has not been enqueued")
@@ -501,7 +565,12 @@ class Pipeline:
             _lib.check(L.vbt_resize_frames(frames_ptr, B, int(src_hw[0]), int(src_hw[1]), 1, self._resized[k].data_ptr(), size, size, 1,
                                            int(bool(swap_rb)), self._dev, S.cuda_stream))
             frames_ptr = self._resized[k].data_ptr()
-        b, s_, c, cnt = self._bufs[k]
+        b, s_, c, cnt = self._bufs[k] if outputs is None else outputs
+        if outputs is not None:
+            for t_, shp_, dt_ in zip(outputs, ((B, 25, 4), (B, 25), (B, 25), (B,)), (torch.float32, torch.float32, torch.float32, torch.int32)):
+                if tuple(t_.shape) != shp_ or t_.dtype != dt_ or not t_.is_contiguous() or t_.device.type != "cuda":
+                    raise ValueError(f"step_runs: outputs must be contiguous device tensors {shp_} {dt_}")
+                t_.record_stream(S)
         _lib.check(L.vbt_detect_async(self.interpreters[k].handle, frames_ptr, B, S.cuda_stream, b.data_ptr(), s_.data_ptr(), c.data_ptr(),
                                       cnt.data_ptr()))
         self._ev_det[k].record(S)
@@ -516,6 +585,13 @@ class Pipeline:
         self._pending.append(k)
         while len(self._pending) >= (1 if self._trk_inline else self.depth):
             self._enqueue_tracker(self._pending.pop(0))
+
+    def join_detectors(self):
+        """The caller's current torch stream waits for every forward enqueued so far (after detector-only steps their outputs are
+        then safe to read on it)."""
+        cur = self._torch.cuda.current_stream()
+        for ev in self._ev_det:
+            cur.wait_event(ev)
 
     def step_seq(self, frames, frame0=None, stream=None, **kw):
         """F consecutive frames of EVERY clip in one step: frames [n_clips, F, H, W, 3] (clip-major, device or pinned host
