@@ -92,3 +92,36 @@ def test_foreign_encoded_tiny_model_hip_equals_oracle(tmp_path, oracle_lib):
             for tid in range(1, it.num_tensors() - 1):
                 if it.materialized(tid):
                     assert np.array_equal(it.read_tensor(tid, 5)[b], det.tensor(tid)), (flags, tid, b)
+
+
+def test_converter_style_full_size_file_at_batch_64(tmp_path, model_path, oracle_lib):
+    """a FULL-SIZE Lite0 file in the conventions of a converter-written one (tests/tflite_fullenc.py: independent
+    encoder, constants ahead of reversed activations, operators in a random topological order, per-channel quantized_dimension, fused
+    activations, FlexBuffers post-process options) goes through `Interpreter(model_path=x.tflite)` at the bench's batch of 64: every
+    detection equals the oracle's on the imported container, every materialised tensor of two frames too, and the plan is as fused as
+    the native container's (the importer untangles the operator order)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tflite_fullenc import ConverterStyleModel
+    from vbt_amd import synth
+    from vbt_amd.interpreter import Interpreter
+    from vbt_amd.tflite_import import convert
+    m = ConverterStyleModel(model_path, order=7).build()
+    tfl, vb = str(tmp_path / "conv_style.tflite"), str(tmp_path / "conv_style.vbtm")
+    open(tfl, "wb").write(m.serialize())
+    convert(tfl, vb)
+    B = 64
+    frames = np.concatenate([synth.clip_frames(s, 2 * s, 4) for s in range(B // 4)])
+    it = Interpreter(model_path=tfl, max_batch=B, flags=8)
+    native = Interpreter(model_path=model_path, max_batch=B, flags=8)
+    assert it.num_launches() <= native.num_launches() + 2
+    boxes, scores, classes, counts = it.detect(frames)
+    ob, os_, oc, on = oracle_lib.run_batch(vb, frames, threads=8)
+    assert np.array_equal(counts, on) and np.array_equal(scores, os_) and np.array_equal(boxes, ob)
+    nb, ns, nc, nn = native.detect(frames)                  # same weights, same quantisation: the native container detects the same
+    assert np.array_equal(counts, nn) and np.array_equal(scores, ns) and np.array_equal(boxes, nb)
+    det = oracle_lib.OracleDetector(vb)
+    for b in (0, B - 1):
+        det.run(frames[b])
+        for tid in range(1, it.num_tensors() - 1):
+            if it.materialized(tid):
+                assert np.array_equal(it.read_tensor(tid, B)[b], det.tensor(tid)), (tid, b)

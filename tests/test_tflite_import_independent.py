@@ -16,6 +16,8 @@ from vbt_amd.container import Container
 from vbt_amd.flatbuf import flex_root
 from vbt_amd.tflite_import import TfModel, convert, is_tflite
 
+from conftest import MODEL_LITE0 as MODEL
+
 
 @pytest.fixture(scope="module")
 def tiny(tmp_path_factory):
@@ -180,3 +182,73 @@ def test_oracle_on_imported_graph_equals_numpy_evaluation_of_the_source_model(ti
     assert count == len(sel) and count > 3
     assert np.array_equal(scores[:count], np.asarray([s for _, s in sel], f32))
     assert np.array_equal(boxes[:count], np.stack([b for b, _ in sel]))
+
+
+# ---- a FULL-SIZE file in the conventions of a converter-written one (tests/tflite_fullenc.py) ----------------------------------
+@pytest.fixture(scope="module")
+def converter_style(tmp_path_factory):
+    from tflite_fullenc import ConverterStyleModel
+    from vbt_amd.tflite_import import convert
+    d = tmp_path_factory.mktemp("conv_style")
+    out = {}
+    for tag, order in (("max", "max"), ("rnd", 7)):
+        m = ConverterStyleModel(MODEL, order=order).build()
+        tfl, vb = str(d / f"{tag}.tflite"), str(d / f"{tag}.vbtm")
+        open(tfl, "wb").write(m.serialize())
+        convert(tfl, vb)
+        out[tag] = (m, tfl, vb)
+    return out
+
+
+def _op_signatures(c):
+    return [(int(r["type"]), int(r["k"]), int(c.tensors[int(r["output"])]["h"]), int(c.tensors[int(r["output"])]["c"])) for r in c.ops]
+
+
+def test_converter_style_file_keeps_every_fusable_chain_contiguous(converter_style):
+    """Operators shuffled (highest native index first / a random topological order), constants ahead of reversed activations in the tensor
+    table: the importer's chain-first ordering must hand the planner the same contiguous expand -> depthwise -> project [-> add] and
+    add [-> add] -> depthwise -> project runs as the native container (the planner fuses only adjacent operators)."""
+    from vbt_amd import spec
+    from vbt_amd.container import Container
+    native = Container(MODEL)
+
+    def chains(c):
+        """(depthwise convs whose producer sits directly before them and whose one consumer, a conv, directly after;
+            of those, the ones fed by an ADD = BiFPN nodes; ADDs directly behind the ADD that produced one of their inputs = partial sums)"""
+        prod = {int(r["output"]): i for i, r in enumerate(c.ops)}
+        cons = {}
+        for i, r in enumerate(c.ops):
+            for t in r["inputs"][:int(r["n_inputs"])]:
+                cons.setdefault(int(t), []).append(i)
+        n_dw = n_node = n_pair = 0
+        for i, r in enumerate(c.ops):
+            typ = int(r["type"])
+            ins = [int(v) for v in r["inputs"][:int(r["n_inputs"])]]
+            if typ == spec.OP_DW and prod.get(ins[0]) == i - 1 and cons.get(int(r["output"])) == [i + 1] and int(c.ops[i + 1]["type"]) == spec.OP_PW:
+                n_dw += 1
+                n_node += int(c.ops[i - 1]["type"]) == spec.OP_ADD
+            if typ == spec.OP_ADD and i >= 1 and int(c.ops[i - 1]["type"]) == spec.OP_ADD and int(c.ops[i - 1]["output"]) in ins:
+                n_pair += 1
+        return n_dw, n_node, n_pair
+
+    want = chains(native)
+    assert want[0] >= 15 + 24 + 30 and want[1] == 24 and want[2] == 9       # MBConv blocks + BiFPN nodes + inner head layers; 3 cells x 8 nodes; 3 three-input sums per cell
+    for tag in ("max", "rnd"):
+        m, tfl, vb = converter_style[tag]
+        c = Container(vb)
+        assert len(c.ops) == len(native.ops) and m.order != sorted(m.order)     # same operators, and the file really is in another order
+        got = chains(c)
+        assert got[0] >= want[0] and got[1:] == want[1:], (tag, got, want)     # (another order may make MORE depthwise convs contiguous, never fewer)
+
+
+def test_converter_style_file_detects_like_the_native_container(converter_style, oracle_lib):
+    """Same weights, same quantisation, another file layout: the oracle on the imported container returns the native container's
+    detections, bit for bit."""
+    from vbt_amd import synth
+    frames = np.concatenate([synth.clip_frames(s, 3 * s, 1) for s in range(2)])
+    want = [oracle_lib.OracleDetector(MODEL).run(f) for f in frames]
+    for tag in ("max", "rnd"):
+        det = oracle_lib.OracleDetector(converter_style[tag][2])
+        for f, (wb, ws, wc, wn) in zip(frames, want):
+            b, s_, c, n = det.run(f)
+            assert n == wn and np.array_equal(s_, ws) and np.array_equal(b, wb), tag

@@ -583,7 +583,11 @@ static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc
   a.NCG = (C + 15) / 16;
   a.KS = (C + 63) / 64;
   const int NT = (to.c + 15) / 16;
-  const int nb = std::max(1, (tin.h * tin.w + 319) / 320);
+  // pixels per band: 320 fills a workgroup's sixteen waves with units (a batch of 64 brings enough bands to fill the GPU); a small
+  // batch leaves most CUs idle, so there a map is cut into more, shorter bands (latency of one band ~ its pixel groups per wave)
+  static const int band_px_env = getenv("VBT_BAND_PX") ? atoi(getenv("VBT_BAND_PX")) : 0;
+  const int band_px = band_px_env > 0 ? band_px_env : (m->max_batch <= 8 ? 128 : 320);
+  const int nb = std::max(1, (tin.h * tin.w + band_px - 1) / band_px);
   a.rows = (tin.h + nb - 1) / nb;
   a.nbands = (tin.h + a.rows - 1) / a.rows;
   a.zx4 = (unsigned)(tin.zero_point & 255) * 0x01010101u;

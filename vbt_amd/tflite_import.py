@@ -292,10 +292,49 @@ def import_tflite(path):
         mult = quant.conv_requant_scales(sx, sw, so)        # XNNPACK: (s_x * s_w[c]) / s_y in float32
         return bias, mult
 
+    # ---- operator order.  A .tflite lists its operators in SOME topological order of the TF graph; which one depends on the converter.
+    # The library's planner fuses chains of consecutive operators (expand -> depthwise -> project -> add, add -> depthwise -> project),
+    # so the body is re-ordered chain-first: an operator whose result has exactly ONE consumer, along one of the edges the planner fuses
+    # (conv -> depthwise, depthwise -> conv, conv -> add, add -> depthwise, add -> add), is followed by that consumer as soon as it is
+    # ready; otherwise the ready operator that comes first in the file runs next.  A file whose chains are contiguous keeps its order
+    # (a result with several consumers - a pyramid level feeding two heads and a resample - never pulls anything forward); one that
+    # interleaves independent branches (two heads layer by layer, a lateral conv between the halves of a block) is untangled.
+    chain_edges = {(BO_CONV_2D, BO_DEPTHWISE_CONV_2D), (BO_DEPTHWISE_CONV_2D, BO_CONV_2D), (BO_CONV_2D, BO_ADD), (BO_ADD, BO_DEPTHWISE_CONV_2D),
+                   (BO_ADD, BO_ADD)}
+    body = [oi for oi in range(len(m.ops)) if oi not in tail_ops]
+    is_act = lambda t: t >= 0 and (t in producer or t == m.inputs[0])      # noqa: E731  (constants carry no ordering)
+    waiting = {oi: {t for t in m.ops[oi].inputs if is_act(t)} for oi in body}
+    avail = {m.inputs[0]}
+    order, left, last = [], set(body), None
+    while left:
+        ready = [oi for oi in sorted(left) if waiting[oi] <= avail]
+        if not ready:
+            raise UnsupportedModel("operators are not in a valid order (an input is never produced)")
+        def completes(oi):
+            # a partial sum (an ADD whose only consumer is another ADD) stays next to the sum it feeds (the planner folds `partial, final`
+            # pairs that are adjacent): it runs only once that second ADD's other input is there - it is neither pulled forward along a
+            # chain nor taken in file order before (unless nothing else is ready)
+            if m.ops[oi].code != BO_ADD:
+                return True
+            cons = consumers.get(m.ops[oi].outputs[0], [])
+            if len(cons) != 1 or m.ops[cons[0]].code != BO_ADD:
+                return True
+            return all(t in avail or t in m.ops[oi].outputs for t in waiting[cons[0]])
+        pick = None
+        if last is not None:
+            only = consumers.get(m.ops[last].outputs[0], []) if len(m.ops[last].outputs) == 1 else []
+            follow = [oi for oi in ready if len(only) == 1 and oi == only[0] and (m.ops[last].code, m.ops[oi].code) in chain_edges and completes(oi)]
+            pick = follow[0] if follow else None
+        if pick is None:
+            pick = next((oi for oi in ready if completes(oi)), ready[0])
+        order.append(pick)
+        left.remove(pick)
+        avail.update(m.ops[pick].outputs)
+        last = pick
+
     in_container = None
-    for oi, op in enumerate(m.ops):
-        if oi in tail_ops:
-            continue
+    for oi in order:
+        op = m.ops[oi]
         where = f"op {oi} ({op.name})"
         if op.code == BO_QUANTIZE:
             ti, to = op.inputs[0], op.outputs[0]
