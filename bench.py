@@ -417,8 +417,11 @@ def extra_measurements(torch, pipe, frames, frames_np, n, K, W, U, fbytes, strea
 
     # ---- H2D-inclusive: uint8 frames in pinned host memory; DataFrame rows of every clip back on the host ----
     Uh = min(U, 16)
-    host = torch.from_numpy(frames_np[:Uh]).pin_memory()                       # [Uh, n, S, S, 3]
+    # (order matters on this stack: with the 33 MB row buffer pinned AFTER the frames, every H2D enqueue of a frame batch blocked the host
+    #  for the length of the copy and the run lost 12 % - 82-87 k against 96-99 k frames/s at K = 20, tools/h2d_k20_probe.py,
+    #  profiles/r04_h2d_pinned_order.md; pinned first, the copies are asynchronous as they should be)
     rows_host = torch.empty(n * pipe.tracker.rows_cap * 64, dtype=torch.uint8).pin_memory()
+    host = torch.from_numpy(frames_np[:Uh]).pin_memory()                       # [Uh, n, S, S, 3]
     reset()
     for i in range(2 * Uh):                     # every pinned slice once (first DMA from a pinned page is slow), twice for the staging ring
         pipe.step(host[i % Uh], stream, track=False)

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <set>
 #include <type_traits>
@@ -1445,53 +1446,118 @@ static bool pwm_mergeable(const vbt_model* m, const Step& s) {
 static void merge_side_convs(vbt_model* m) {
   static const bool off = getenv("VBT_NO_PW_MERGE") != nullptr;
   if (off || (m->flags & (VBT_MODEL_NO_FUSION | VBT_MODEL_NO_PW_MERGE))) return;
-  const int ns = (int)m->steps.size();
-  auto written_from = [&](int tensor, int i0) {   // is `tensor` written by a step at or after i0 ?
-    for (int j = i0; j < ns; j++) {
-      const Step& s = m->steps[j];
-      if (m->ops[s.op].output == tensor) return true;
-      for (const Step& ms : s.members) if (m->ops[ms.op].output == tensor) return true;
+  const int ns = (int)m->steps.size(), no = (int)m->ops.size();
+  // which step runs which graph op: the ops a step names, then (absorbed resamples / partial sums) the step of their consumer
+  std::vector<int> step_of(no, -1);
+  std::function<void(const Step&, int)> claim = [&](const Step& s, int i) {
+    for (int o : {s.op, s.e_op, s.d_op, s.p_op, s.a_op, s.res_op, s.sum_op})
+      if (o >= 0 && o < no) step_of[o] = i;
+    for (const Step& ms : s.members) claim(ms, i);
+  };
+  for (int i = 0; i < ns; i++) claim(m->steps[i], i);
+  std::vector<std::vector<int>> readers(m->tensors.size());
+  std::vector<int> producer(m->tensors.size(), -1);
+  for (int o = 0; o < no; o++) {
+    producer[m->ops[o].output] = o;
+    for (int k = 0; k < m->ops[o].n_inputs; k++) readers[m->ops[o].inputs[k]].push_back(o);
+  }
+  for (int o = no - 1; o >= 0; o--)
+    if (step_of[o] < 0) {
+      int best = ns;
+      for (int r : readers[m->ops[o].output]) if (step_of[r] >= 0) best = std::min(best, step_of[r]);
+      step_of[o] = best < ns ? best : -1;
+    }
+  for (int o = 0; o < no; o++) if (step_of[o] < 0) return;    // an op nobody runs: leave the plan alone
+  auto made_at = [&](int tensor) { return producer[tensor] >= 0 ? step_of[producer[tensor]] : -1; };
+  auto first_read = [&](int tensor, int except_op = -1) {
+    int f = ns;
+    for (int r : readers[tensor]) if (r != except_op) f = std::min(f, step_of[r]);
+    return f;
+  };
+  // the P6 / P7 chain: a conv whose output feeds a 3x3/2 max pool that feeds another one (steps of their own)
+  auto pools_of = [&](int conv_step, int* k1, int* k2) {
+    const int t0 = m->ops[m->steps[conv_step].op].output;
+    for (int r1 : readers[t0]) {
+      const OpRec& p1 = m->ops[r1];
+      if (p1.type != OP_MAXPOOL || p1.k != 3 || p1.stride != 2 || m->steps[step_of[r1]].family != F_MAXPOOL) continue;
+      for (int r2 : readers[p1.output]) {
+        const OpRec& p2 = m->ops[r2];
+        if (p2.type != OP_MAXPOOL || p2.k != 3 || p2.stride != 2 || m->steps[step_of[r2]].family != F_MAXPOOL) continue;
+        const TensorRec &to = m->tensors[t0], &t1 = m->tensors[p1.output];
+        if (to.c % 16 != 0 || (size_t)((to.h * to.w * to.c + 15) & ~15) + (size_t)t1.h * t1.w * t1.c > 64 * 1024) continue;
+        *k1 = step_of[r1]; *k2 = step_of[r2];
+        return true;
+      }
     }
     return false;
   };
-  int best = -1;
+  // every stand-alone conv as the anchor (the slot the merged launch takes): member j fits when its input exists before the anchor
+  // and nobody reads its output before the anchor has run
+  int best = -1, best_chain = -1, bk1 = -1, bk2 = -1;
   std::vector<int> best_set;
-  for (int i = 0; i < ns; i++) {
-    if (!pwm_mergeable(m, m->steps[i])) continue;
-    std::vector<int> set{i};
-    for (int j = i + 1; j < ns && (int)set.size() < PWM_MAX; j++)
-      if (pwm_mergeable(m, m->steps[j]) && !written_from(m->ops[m->steps[j].op].inputs[0], i)) set.push_back(j);
-    if (set.size() >= best_set.size() && set.size() >= 2) { best = i; best_set = set; }
+  for (int a = 0; a < ns; a++) {
+    if (!pwm_mergeable(m, m->steps[a])) continue;
+    std::vector<int> set;
+    int chain = -1, k1 = -1, k2 = -1;
+    for (int j = 0; j < ns && (int)set.size() < PWM_MAX; j++) {
+      if (!pwm_mergeable(m, m->steps[j])) continue;
+      const OpRec& cj = m->ops[m->steps[j].op];
+      if (j > a && made_at(cj.inputs[0]) >= a) continue;            // hoisted to the anchor: its input must exist by then
+      int c1, c2;
+      if (chain < 0 && pools_of(j, &c1, &c2)) {
+        // the pools come along: the conv's other readers and the pools' readers must all run after the anchor
+        const OpRec &p1 = m->ops[m->steps[c1].op], &p2 = m->ops[m->steps[c2].op];
+        if (first_read(cj.output, m->steps[c1].op) > a && first_read(p1.output, m->steps[c2].op) > a && first_read(p2.output) > a) {
+          chain = j; k1 = c1; k2 = c2;
+          set.push_back(j);
+          continue;
+        }
+      }
+      if (first_read(cj.output) > a) set.push_back(j);               // (sunk or hoisted: nobody reads its output before the anchor has run)
+    }
+    // no member may read another member's output (they run side by side)
+    for (bool again = true; again;) {
+      again = false;
+      for (size_t q = 0; q < set.size(); q++) {
+        const int src = made_at(m->ops[m->steps[set[q]].op].inputs[0]);
+        if (src >= 0 && std::find(set.begin(), set.end(), src) != set.end()) {
+          if (set[q] == chain) chain = -1;
+          set.erase(set.begin() + q);
+          again = true;
+          break;
+        }
+      }
+    }
+    if (std::find(set.begin(), set.end(), a) == set.end()) continue;
+    const int score = (int)set.size() + (chain >= 0 ? 2 : 0);
+    const int best_score = (int)best_set.size() + (best_chain >= 0 ? 2 : 0);
+    if (set.size() >= 2 && score >= best_score) { best = a; best_set = set; best_chain = chain; bk1 = k1; bk2 = k2; }
   }
   if (best < 0) return;
-  Step merged = m->steps[best];
+  if (best_chain >= 0) {   // the chain problem goes first (pw_multi_kernel: problem 0)
+    best_set.erase(std::find(best_set.begin(), best_set.end(), best_chain));
+    best_set.insert(best_set.begin(), best_chain);
+  }
+  Step merged = m->steps[best_set[0]];
   merged.members.clear();
   merged.alg_bytes_per_frame = merged.weight_bytes = merged.macs_per_frame = 0;
+  merged.nbp = 0;   // (1: problem 0 carries its two pools)
   std::vector<char> drop(ns, 0);
   for (int j : best_set) {
     merged.members.push_back(m->steps[j]);
     merged.alg_bytes_per_frame += m->steps[j].alg_bytes_per_frame;
     merged.weight_bytes += m->steps[j].weight_bytes;
     merged.macs_per_frame += m->steps[j].macs_per_frame;
-    if (j != best) drop[j] = 1;
+    drop[j] = 1;
   }
-  // the anchor's pools: steps best + 1 / best + 2 = MAX_POOL 3x3/2 of the anchor's output and of that pool
-  merged.nbp = 0;   // (1: the anchor carries its two pools)
-  if (best + 2 < ns && m->steps[best + 1].family == F_MAXPOOL && m->steps[best + 2].family == F_MAXPOOL) {
-    const OpRec &c = m->ops[m->steps[best].op], &p1 = m->ops[m->steps[best + 1].op], &p2 = m->ops[m->steps[best + 2].op];
-    const TensorRec& to = m->tensors[c.output];
-    const TensorRec& t1 = m->tensors[p1.output];
-    const size_t lds = (size_t)((to.h * to.w * to.c + 15) & ~15) + (size_t)t1.h * t1.w * t1.c;
-    if (p1.inputs[0] == c.output && p2.inputs[0] == p1.output && p1.k == 3 && p1.stride == 2 && p2.k == 3 && p2.stride == 2 &&
-        to.c % 16 == 0 && lds <= 64 * 1024) {
-      merged.nbp = 1;
-      merged.lds_bytes = (int)lds;
-      merged.members.push_back(m->steps[best + 1]);
-      merged.members.push_back(m->steps[best + 2]);
-      for (int k = 1; k <= 2; k++) {
-        merged.alg_bytes_per_frame += m->steps[best + k].alg_bytes_per_frame;
-        drop[best + k] = 1;
-      }
+  if (best_chain >= 0) {
+    const TensorRec &to = m->tensors[m->ops[m->steps[best_chain].op].output], &t1 = m->tensors[m->ops[m->steps[bk1].op].output];
+    merged.nbp = 1;
+    merged.lds_bytes = (int)(((to.h * to.w * to.c + 15) & ~15) + t1.h * t1.w * t1.c);
+    for (int k : {bk1, bk2}) {
+      merged.members.push_back(m->steps[k]);
+      merged.alg_bytes_per_frame += m->steps[k].alg_bytes_per_frame;
+      drop[k] = 1;
     }
   }
   std::vector<Step> out;
