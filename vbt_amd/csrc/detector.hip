@@ -587,7 +587,7 @@ static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc
   // pixels per band: 320 fills a workgroup's sixteen waves with units (a batch of 64 brings enough bands to fill the GPU); a small
   // batch leaves most CUs idle, so there a map is cut into more, shorter bands (latency of one band ~ its pixel groups per wave)
   static const int band_px_env = getenv("VBT_BAND_PX") ? atoi(getenv("VBT_BAND_PX")) : 0;
-  const int band_px = band_px_env > 0 ? band_px_env : (m->max_batch <= 8 ? 128 : 320);
+  const int band_px = band_px_env > 0 ? band_px_env : (m->max_batch <= 8 ? 64 : 320);   // (batch 1 / 8, four forwards in flight: 64 px +3-5 % over 320, tools/band_px_sweep.sh)
   const int nb = std::max(1, (tin.h * tin.w + band_px - 1) / band_px);
   a.rows = (tin.h + nb - 1) / nb;
   a.nbands = (tin.h + a.rows - 1) / a.rows;
