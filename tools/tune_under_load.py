@@ -62,6 +62,9 @@ def score(lines, reps=2, K=300):
 lines = open(plan_in).read().split("\n")
 while lines and not lines[-1]:
     lines.pop()
+if lines and lines[0].startswith("VBTPLAN2"):      # format 2 names the kernel families: the search edits bare indices (format 1, still
+    lines[0] = lines[0].split()[1]                 # loadable); re-create the library once with VBT_PLAN_CONVERT=1 to get the names back
+    lines[1:] = [" ".join(tok.rsplit(":", 1)[-1] for tok in ln.split()) for ln in lines[1:]]
 # candidates: (1-based line, [texts])
 cands = []
 for ln, text in enumerate(lines, 1):

@@ -2270,18 +2270,45 @@ static void autotune(vbt_model* m) {
   (void)hipDeviceSynchronize();
 }
 
-// Plan cache: "<ngroups>" then per group "<chosen> <nsteps> <variant>..." for the chosen alternative.
+// Plan cache.  Format 2 (written): "VBTPLAN2 <ngroups>" then per group "<chosen alternative> <nsteps> <family>:<variant> ..." - the
+// kernel family of every step of the chosen alternative by NAME, so that a file tuned for another build of the planner (an
+// alternative added, removed or re-ordered: the bare indices of format 1 would still load and silently select other kernels) is
+// refused and the plan re-tuned.  Format 1 ("<ngroups>" then "<chosen> <nsteps> <variant>...") is still read - the group and step
+// counts are all it can be checked against - and re-written in format 2 when VBT_PLAN_CONVERT is set.
 static bool load_plan(vbt_model* m, const char* path) {
   FILE* f = fopen(path, "r");
   if (!f) return false;
+  char head[32] = "";
   int ng = 0;
-  bool ok = fscanf(f, "%d", &ng) == 1 && ng == (int)m->groups.size();
+  bool v2 = false;
+  bool ok = fscanf(f, "%31s", head) == 1;
+  if (ok && strcmp(head, "VBTPLAN2") == 0) { v2 = true; ok = fscanf(f, "%d", &ng) == 1; }
+  else if (ok) ng = atoi(head);
+  ok = ok && ng == (int)m->groups.size();
   std::vector<std::pair<int, std::vector<int>>> sel;
   for (int gi = 0; ok && gi < ng; gi++) {
     int ch = 0, ns = 0;
     ok = fscanf(f, "%d %d", &ch, &ns) == 2 && ch >= 0 && ch < (int)m->groups[gi].alts.size() && ns == (int)m->groups[gi].alts[ch].steps.size();
     std::vector<int> v(ok ? ns : 0);
-    for (int i = 0; ok && i < ns; i++) ok = fscanf(f, "%d", &v[i]) == 1;
+    for (int i = 0; ok && i < ns; i++) {
+      if (v2) {
+        char tok[96] = "";
+        ok = fscanf(f, "%95s", tok) == 1;
+        char* colon = ok ? strrchr(tok, ':') : nullptr;
+        ok = ok && colon != nullptr;
+        if (ok) {
+          *colon = 0;
+          v[i] = atoi(colon + 1);
+          const int fam = m->groups[gi].alts[ch].steps[i].family;
+          if (strcmp(tok, kFamilyName[fam]) != 0) {
+            fprintf(stderr, "[vbt] plan %s: group %d step %d is '%s' in the file, '%s' in this library - plan refused, re-tuning\n", path, gi, i, tok, kFamilyName[fam]);
+            ok = false;
+          }
+        }
+      } else {
+        ok = fscanf(f, "%d", &v[i]) == 1;
+      }
+    }
     sel.push_back({ch, v});
   }
   fclose(f);
@@ -2296,11 +2323,11 @@ static bool load_plan(vbt_model* m, const char* path) {
 static void save_plan(const vbt_model* m, const char* path) {
   FILE* f = fopen(path, "w");
   if (!f) return;
-  fprintf(f, "%d\n", (int)m->groups.size());
+  fprintf(f, "VBTPLAN2 %d\n", (int)m->groups.size());
   for (const Group& g : m->groups) {
     const Alt& a = g.alts[g.chosen];
     fprintf(f, "%d %d", g.chosen, (int)a.steps.size());
-    for (const Step& st : a.steps) fprintf(f, " %d", st.variant);
+    for (const Step& st : a.steps) fprintf(f, " %s:%d", kFamilyName[st.family], st.variant);
     fprintf(f, "\n");
   }
   fclose(f);
@@ -2538,6 +2565,8 @@ int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, 
     if (!pf || !load_plan(m, path)) {
       autotune(m);
       if (pf) save_plan(m, path);
+    } else if (getenv("VBT_PLAN_CONVERT")) {
+      save_plan(m, path);       // a format-1 file comes back in format 2 (same choices, kernel families by name)
     }
   }
   finalize_plan(m);
