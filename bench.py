@@ -56,7 +56,7 @@ MFMA_I8_PEAK = 5.0e15      # op/s dense: int8 MFMA = 2x the bf16 rate per clock 
 PLAN_LITE0 = os.path.join(ROOT, "profiles", "plan_lite0")
 PLAN_LITE2 = os.path.join(ROOT, "profiles", "plan_lite2")
 os.environ.setdefault("VBT_PLAN_FILE", PLAN_LITE0)
-COUNTERS = [os.path.join(ROOT, "profiles", f) for f in ("r03_counters.json", "r02_counters.json")]
+COUNTERS = [os.path.join(ROOT, "profiles", f) for f in ("r04_counters.json", "r03_counters.json")]
 # VBT_BENCH_MODEL: rehearsal knob; the contract line is always Lite0
 MODEL = os.environ.get("VBT_BENCH_MODEL", os.path.join(ROOT, "models", "efficientdet_lite0_synth.vbtm"))
 MODEL_LITE2 = os.path.join(ROOT, "models", "efficientdet_lite2_synth.vbtm")

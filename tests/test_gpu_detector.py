@@ -1,4 +1,6 @@
 """GPU parity: HIP detector vs the CPU oracle, bit-exact (integer pipeline) through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -217,3 +219,29 @@ def test_integer_add_ties_bit_exact_in_every_fused_path(tie_model, oracle_lib, f
     for k in range(B):
         ob, os_, oc, on = want[k]
         assert counts[k] == on and np.array_equal(scores[k], os_) and np.array_equal(boxes[k], ob)
+
+
+def test_plan_file_with_a_foreign_kernel_name_is_refused(model_path, tmp_path, monkeypatch):
+    """Plan files name the kernel family of every step (format 2): a file whose names do not fit this build of the planner - tuned for
+    another set of alternatives - must not select kernels by bare index; the library refuses it, re-tunes and re-writes it.  A format-1
+    file (indices only) and the pinned format-2 file both load unchanged."""
+    import shutil
+    from conftest import ROOT
+    from vbt_amd.interpreter import Interpreter
+    pinned = os.path.join(ROOT, "profiles", "plan_lite0.b8.f0")
+    good = open(pinned).read()
+    assert good.startswith("VBTPLAN2 ")
+    prefix = str(tmp_path / "plan")
+    monkeypatch.setenv("VBT_PLAN_FILE", prefix)
+    shutil.copy(pinned, prefix + ".b8.f0")
+    Interpreter(model_path, max_batch=8)
+    assert open(prefix + ".b8.f0").read() == good                       # accepted as it is
+    bad = good.replace("fused_mbconv:", "fused_mbconv_of_another_build:", 1)
+    open(prefix + ".b8.f0", "w").write(bad)
+    it = Interpreter(model_path, max_batch=8)
+    after = open(prefix + ".b8.f0").read()
+    assert after != bad and after.startswith("VBTPLAN2 ") and "of_another_build" not in after and it.num_launches() < 70
+    legacy = "\n".join([good.split("\n")[0].split()[1]] + [" ".join(t.rsplit(":", 1)[-1] for t in ln.split()) for ln in good.split("\n")[1:]])
+    open(prefix + ".b8.f0", "w").write(legacy)
+    Interpreter(model_path, max_batch=8)
+    assert open(prefix + ".b8.f0").read() == legacy                     # format 1 still loads (and is left alone without VBT_PLAN_CONVERT)

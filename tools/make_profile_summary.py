@@ -105,12 +105,12 @@ def summarize(src, pre, out_tag, title, plan, alg_mb_forward, alg_mb_frame, benc
                     f"detector only {bench['splits']['detect_only']['frames_per_s']:.0f} frames/s; OC-SORT step {bench['splits']['track_only']['us_per_step']:.1f} us per 64 clips.\n")
             cfgs = bench.get("configs") or {}
             if cfgs:
-                f.write("Other configurations in the same line: " + "; ".join(f"{k} {v['frames_per_s']:.0f} frames/s ({100 * v['roofline_frac_8d']:.1f} % of the 8d roofline)"
+                f.write("Other configurations in the same line: " + "; ".join(f"{k} {v['frames_per_s']:.0f} frames/s" + (f" ({100 * v['roofline_frac_8d']:.1f} % of the 8d roofline)" if "roofline_frac_8d" in v else "")
                                                                               for k, v in cfgs.items() if "frames_per_s" in v) + ".\n")
         if k20 is not None:
             f.write(f"Driver-style `python bench.py --steps 20 --warmup 5`: **{k20['value']:.0f} frames/s, {k20['ms_per_step']:.3f} ms/step** "
                     f"(timed region: enqueue {k20['timed_region_ms']['enqueue']:.2f} ms, clip close incl. pipeline drain {k20['timed_region_ms']['clip_close']:.2f} ms); "
-                    f"cold start (fresh first process, no settle phase) {((k20.get('cold_start') or {}).get('value') or 0):.0f} frames/s; "
+                    f"the same run repeated after a clock-settle phase {k20.get('value_settled', 0):.0f} frames/s; "
                     f"H2D-inclusive with the same W / K {k20.get('value_h2d_inclusive', 0):.0f} frames/s.\n")
         f.write("Under `rocprofv3 --kernel-trace` dispatches serialise, so the overlap between the forwards in flight is lost while profiling: "
                 f"trace wall per step {wall3:.3f} ms (depth 3) / {wall1:.3f} ms (`VBT_PIPELINE_DEPTH=1`).\n\n")

@@ -16,6 +16,15 @@ namespace vbt {
 
 void set_error(const char* fmt, ...);
 
+// roctx ranges around the host-side enqueue of the path's three stages (detect incl. decode + NMS, track, clip close): with
+// VBT_ROCTX=1 the library loads librocprofiler-sdk-roctx.so at the first use and `rocprofv3 --marker-trace` shows
+// "vbt:detect" / "vbt:track" / "vbt:finish" next to the kernels they enqueue; without it every call is one branch.
+struct RoctxRange {
+  explicit RoctxRange(const char* name);
+  ~RoctxRange();
+  bool on;
+};
+
 #define VBT_HIP_CHECK(expr)                                                              \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \

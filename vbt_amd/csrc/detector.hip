@@ -2371,6 +2371,7 @@ static int enqueue_forward(vbt_model* m, const uint8_t* frames_dev, int B, hipSt
 // Forward = eager launches, or (small batches: the 120-odd launches are host-bound) replay of a captured hipGraph.
 static int forward(vbt_model* m, const uint8_t* frames_dev, int B, hipStream_t st, float* boxes, float* scores, float* classes,
                    int* counts) {
+  RoctxRange range("vbt:detect");
   if (m->pool_dirty) { const int rc = flush_uploads(m); if (rc) return rc; }   // (never inside a stream capture)
   if (B > m->graph_max_batch || !m->cap_stream) return enqueue_forward(m, frames_dev, B, st, boxes, scores, classes, counts, nullptr);
   vbt_model::GraphKey key{frames_dev, boxes, scores, classes, counts, B};

@@ -1,5 +1,7 @@
 // Frame plumbing in front of the detector (gfx950): assembling a detector batch from frames that live in different
 // places of device memory.  HBM-bound byte moves: 16 bytes per lane, consecutive lanes on consecutive addresses.
+#include <dlfcn.h>
+
 #include "common.h"
 
 namespace vbt {
@@ -18,6 +20,29 @@ __global__ __launch_bounds__(256) void gather_frames_kernel(uint4* __restrict__ 
   for (int k = 0; k < per; k++, i += 256)
     if (i < frame_vec) d[i] = s[i];
 }
+
+// ---- roctx ranges (common.h): resolved lazily with dlopen, so that the library has no link-time dependency on the profiler SDK ----
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static int g_roctx_state = 0;   // 0 = not tried, 1 = on, -1 = off
+static bool roctx_ready() {
+  if (g_roctx_state == 0) {
+    g_roctx_state = -1;
+    const char* e = getenv("VBT_ROCTX");
+    if (e && e[0] == '1') {
+      void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h) {
+        g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) g_roctx_state = 1;
+      }
+    }
+  }
+  return g_roctx_state == 1;
+}
+RoctxRange::RoctxRange(const char* name) : on(roctx_ready()) { if (on) g_roctx_push(name); }
+RoctxRange::~RoctxRange() { if (on) g_roctx_pop(); }
 
 }  // namespace vbt
 
