@@ -72,7 +72,34 @@ struct TrackParams {
 // ------------------------------------------------------------------------------------------
 // Kalman filter pieces (see header comment)
 // ------------------------------------------------------------------------------------------
-__device__ inline void kf_predict(Trk& k, double q44, double q66) {
+// The filter state proper as a LOCAL value: x, the three 2x2 covariance blocks and the variance of r.  predict / update work on a copy
+// in registers that is loaded from the track once and stored back once: through a `Trk&` into LDS or global memory the compiler has to
+// assume that every store may change what the next load reads (the detection, the observation history and the state are all plain
+// double arrays), so the filter arithmetic ran as a chain of store -> wait -> load.
+struct KfCore {
+  double x[7];
+  double B[3][4];
+  double Pr;
+};
+__device__ __forceinline__ void core_load(KfCore& c, const Trk& k) {
+#pragma unroll
+  for (int i = 0; i < 7; i++) c.x[i] = k.x[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) c.B[i][j] = k.B[i][j];
+  c.Pr = k.Pr;
+}
+__device__ __forceinline__ void core_store(Trk& k, const KfCore& c) {
+#pragma unroll
+  for (int i = 0; i < 7; i++) k.x[i] = c.x[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) k.B[i][j] = c.B[i][j];
+  k.Pr = c.Pr;
+}
+__device__ __forceinline__ void kf_predict(KfCore& k, double q44, double q66) {
 #pragma unroll
   for (int i = 0; i < 3; i++) k.x[i] = k.x[i] + k.x[i + 4];
 #pragma unroll
@@ -87,7 +114,7 @@ __device__ inline void kf_predict(Trk& k, double q44, double q66) {
   k.Pr = k.Pr + 1.0;
 }
 
-__device__ inline void kf_update_math(Trk& k, const double z[4]) {
+__device__ __forceinline__ void kf_update_math(KfCore& k, const double z[4]) {
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const double Rc = i == 2 ? 10.0 : 1.0;
@@ -116,18 +143,18 @@ __device__ inline void kf_update_math(Trk& k, const double z[4]) {
   k.Pr = (omk * k.Pr) * omk + (kk * 10.0) * kk;
 }
 
-// kf.update(z) with OC-SORT's freeze / unfreeze (observation-centric re-update)
-__device__ inline void kf_update(Trk& k, const double* z, double q44, double q66) {
+// kf.update(z) with OC-SORT's freeze / unfreeze (observation-centric re-update); c = the track's filter state (registers)
+__device__ inline void kf_update(Trk& k, KfCore& c, const double* z, double q44, double q66) {
   k.gap += 1;  // one more entry in history_obs since the last real observation
   if (z == nullptr) {
     if (k.observed) {  // first miss: freeze
 #pragma unroll
-      for (int i = 0; i < 7; i++) k.sx[i] = k.x[i];
+      for (int i = 0; i < 7; i++) k.sx[i] = c.x[i];
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) k.sB[i][j] = k.B[i][j];
-      k.sPr = k.Pr;
+        for (int j = 0; j < 4; j++) k.sB[i][j] = c.B[i][j];
+      k.sPr = c.Pr;
       k.has_saved = 1;
     }
     k.observed = 0;
@@ -136,12 +163,12 @@ __device__ inline void kf_update(Trk& k, const double* z, double q44, double q66
   double zl[4] = {z[0], z[1], z[2], z[3]};
   if (!k.observed && k.has_saved) {  // unfreeze: replay a linear virtual trajectory over the gap
 #pragma unroll
-    for (int i = 0; i < 7; i++) k.x[i] = k.sx[i];
+    for (int i = 0; i < 7; i++) c.x[i] = k.sx[i];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j < 4; j++) k.B[i][j] = k.sB[i][j];
-    k.Pr = k.sPr;
+      for (int j = 0; j < 4; j++) c.B[i][j] = k.sB[i][j];
+    c.Pr = k.sPr;
     double x1 = k.last_z[0], y1 = k.last_z[1], s1 = k.last_z[2], r1 = k.last_z[3];
     double w1 = sqrt(s1 * r1), h1 = sqrt(s1 / r1);
     double x2 = z[0], y2 = z[1], s2 = z[2], r2 = z[3];
@@ -153,14 +180,14 @@ __device__ inline void kf_update(Trk& k, const double* z, double q44, double q66
       double f = (double)(i + 1);
       double xx = x1 + f * dx, yy = y1 + f * dy, ww = w1 + f * dw, hh = h1 + f * dh;
       double vz[4] = {xx, yy, ww * hh, ww / hh};
-      kf_update_math(k, vz);
-      if (i != gap - 1) kf_predict(k, q44, q66);
+      kf_update_math(c, vz);
+      if (i != gap - 1) kf_predict(c, q44, q66);
       else { zl[0] = vz[0]; zl[1] = vz[1]; zl[2] = vz[2]; zl[3] = vz[3]; }  // history ends with the virtual box
     }
     k.has_saved = 0;
   }
   k.observed = 1;
-  kf_update_math(k, z);
+  kf_update_math(c, z);
   k.last_z[0] = zl[0]; k.last_z[1] = zl[1]; k.last_z[2] = zl[2]; k.last_z[3] = zl[3];
   k.gap = 0;
 }
@@ -187,8 +214,11 @@ __device__ inline bool obs_sum_negative(const Trk& k) {
 }
 
 // KalmanBoxTracker.update(bbox)   (bbox = x1,y1,x2,y2,score ; cls)
-__device__ inline void trk_update(Trk& k, const double* det, double q44, double q66, int delta_t) {
-  if (det == nullptr) { kf_update(k, nullptr, q44, q66); return; }
+__device__ inline void trk_update(Trk& k, const double* det_in, double q44, double q66, int delta_t) {
+  KfCore c;
+  core_load(c, k);
+  if (det_in == nullptr) { kf_update(k, c, nullptr, q44, q66); return; }     // (update(None) leaves the filter state as it is)
+  const double det[6] = {det_in[0], det_in[1], det_in[2], det_in[3], det_in[4], det_in[5]};   // in registers before the first store
   k.conf = det[4];
   k.cls = det[5];
   if (!obs_sum_negative(k)) {
@@ -198,7 +228,8 @@ __device__ inline void trk_update(Trk& k, const double* det, double q44, double 
       if (a >= 0 && k.obs_age[a & 3] == a) { prev = k.obs[a & 3]; break; }
     }
     if (!prev) prev = k.last_obs;
-    double cx1 = (prev[0] + prev[2]) / 2.0, cy1 = (prev[1] + prev[3]) / 2.0;
+    const double p0 = prev[0], p1 = prev[1], p2 = prev[2], p3 = prev[3];
+    double cx1 = (p0 + p2) / 2.0, cy1 = (p1 + p3) / 2.0;
     double cx2 = (det[0] + det[2]) / 2.0, cy2 = (det[1] + det[3]) / 2.0;
     double sy = cy2 - cy1, sx = cx2 - cx1;
     double norm = sqrt(sy * sy + sx * sx) + 1e-6;
@@ -215,7 +246,8 @@ __device__ inline void trk_update(Trk& k, const double* det, double q44, double 
   k.hit_streak += 1;
   double z[4];
   bbox_to_z(det, z);
-  kf_update(k, z, q44, q66);
+  kf_update(k, c, z, q44, q66);
+  core_store(k, c);
 }
 
 __device__ inline double iou_xyxy(const double* a, const double* b) {
@@ -292,6 +324,12 @@ __device__ __forceinline__ int wave_max_i32(int x) {
   return __builtin_amdgcn_readlane(x, 63);
 }
 
+#ifdef VBT_NO_LAP_SMALL
+__device__ __forceinline__ bool lap_small_off() { return true; }
+#else
+__device__ __forceinline__ bool lap_small_off() { return false; }
+#endif
+
 struct LapShared {
   double u[MAXT];
   double spc[MAXT];
@@ -301,8 +339,87 @@ struct LapShared {
   int remaining[MAXT];
 };
 
+// The same solver for 2..4 rows (a frame of the reference holds at most 3 plates; the second association sees even fewer rows) with
+// every array in registers: the per-row state (duals u, col4row) is wave-uniform, the per-column state (dual v, row4col, path,
+// shortest path cost, position in `remaining`) belongs to the column's lane, `remaining[index]` is "the lane whose position is
+// index" (a ballot), and a value of another lane comes over the scalar path (v_readlane).  No LDS array, no barrier inside; the
+// arithmetic - ((minVal + c) - u) - v, the dual updates, the tie rule - is the general solver's, statement for statement.
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  const unsigned long long v = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ void lap_small(const double* C, int ld, bool tr, int nr, int nc, int* row2col, int lane) {
+  const double INF = __builtin_inf();
+  const bool col = lane < nc;
+  double cst[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) cst[q] = (col && q < nr) ? (tr ? C[lane * ld + q] : C[q * ld + lane]) : INF;
+  double u[4] = {0.0, 0.0, 0.0, 0.0};
+  int c4r[4] = {-1, -1, -1, -1};
+  double v = 0.0;
+  int r4c = -1, path = -1;
+  auto sel_d = [](const double a[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3]; };
+  for (int cur = 0; cur < nr; cur++) {
+    double minVal = 0.0;
+    int num_rem = nc;
+    int pos = col ? nc - 1 - lane : -1;
+    double spc = INF;
+    unsigned sr = 0u;
+    int i = cur, sink = -1;
+    while (sink == -1) {
+      sr |= 1u << i;
+      const double ui = sel_d(u, i);
+      const bool active = col && pos >= 0;
+      if (active) {
+        const double c = sel_d(cst, i);
+        const double r = ((minVal + c) - ui) - v;
+        if (r < spc) { path = i; spc = r; }
+      }
+      const double lowest = wave_min_f64(active ? spc : INF);
+      const bool cand = active && spc == lowest;
+      const unsigned long long un = __ballot(cand && r4c == -1);
+      int key;  // choose: unassigned candidates -> max position, else min position
+      if (un) key = (cand && r4c == -1) ? pos : -1;
+      else key = cand ? -pos : -(1 << 20);
+      key = wave_max_i32(key);
+      const int index = un ? key : -key;
+      minVal = lowest;
+      const int j = __ffsll((long long)__ballot(active && pos == index)) - 1;     // remaining[index]
+      const int jrow = __builtin_amdgcn_readlane(r4c, j);
+      if (jrow == -1) sink = j; else i = jrow;
+      num_rem -= 1;
+      const int jl = __ffsll((long long)__ballot(active && pos == num_rem)) - 1;  // remaining[num_rem]
+      if (lane == j) pos = -1;
+      if (lane == jl && jl != j) pos = index;
+    }
+    // ---- dual updates ----
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q >= nr) continue;
+      if (q == cur) u[q] += minVal;
+      else if ((sr >> q) & 1u) u[q] += minVal - readlane_f64(spc, c4r[q]);
+    }
+    if (col && pos < 0) v -= minVal - spc;
+    // ---- augment ----
+    int j = sink;
+    while (true) {
+      const int ii = __builtin_amdgcn_readlane(path, j);
+      if (lane == j) r4c = ii;
+      const int t = ii == 0 ? c4r[0] : ii == 1 ? c4r[1] : ii == 2 ? c4r[2] : c4r[3];
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (q == ii) c4r[q] = j;
+      j = t;
+      if (ii == cur) break;
+    }
+  }
+  if (lane < nr) row2col[lane] = lane == 0 ? c4r[0] : lane == 1 ? c4r[1] : lane == 2 ? c4r[2] : c4r[3];
+  __syncthreads();
+}
+
 __device__ void lap_solve(const double* C, int ld, bool tr, int nr, int nc, int* row2col, LapShared& S, int lane) {
   const double INF = __builtin_inf();
+  if (nr >= 2 && nr <= 4 && !lap_small_off()) { lap_small(C, ld, tr, nr, nc, row2col, lane); return; }
   if (nr == 1) {
     // One row (OC-SORT's second association usually has one unmatched detection): the first augmenting path of the solver
     // ends at the cheapest column; among equal costs it takes the LAST one it scans, and it scans remaining[] = nc-1 ... 0,
@@ -415,13 +532,16 @@ __device__ void ocsort_step(ClipState& st, Row* rows, int rows_cap, StepShared& 
   bool isnan_box = false;
   if (lane < T) {
     Trk& k = st.trk[st.order[lane]];
-    if ((k.x[6] + k.x[2]) <= 0.0) k.x[6] *= 0.0;
-    kf_predict(k, q44, q66);
+    KfCore c;
+    core_load(c, k);
+    if ((c.x[6] + c.x[2]) <= 0.0) c.x[6] *= 0.0;
+    kf_predict(c, q44, q66);
+    core_store(k, c);
     k.age += 1;
     if (k.time_since_update > 0) k.hit_streak = 0;
     k.time_since_update += 1;
     double bx[4];
-    x_to_bbox(k.x, bx);
+    x_to_bbox(c.x, bx);
     isnan_box = (bx[0] != bx[0]) || (bx[1] != bx[1]) || (bx[2] != bx[2]) || (bx[3] != bx[3]);
 #pragma unroll
     for (int i = 0; i < 4; i++) sh.tbox[lane][i] = bx[i];
