@@ -344,6 +344,47 @@ def test_tracker_on_the_detector_streams_gives_the_same_rows(model_path, monkeyp
     assert a[5] == b[5]
 
 
+@pytest.mark.parametrize("n,depth", [(1, 4), (3, 2), (8, 3)])
+def test_deferred_tracker_steps_give_the_same_rows(model_path, monkeypatch, n, depth):
+    """Small batches hand the detections of `depth` consecutive steps to ONE launch of the time-batched walk (VBT_TRACKER_DEFER,
+    default on for <= 8 clips) instead of one tracker launch per step: identical rows, export ids and phases - with a group cut
+    short by skip_frames() (another frame stride), by a step with a clip map, by a read of the rows in the middle, and with
+    a partial last group."""
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    T = 27
+    frames = np.stack([np.stack([synth.render(synth.background(90 + c), 5 * c + t) for c in range(n)]) for t in range(T)])
+    fd = torch.from_numpy(frames).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("VBT_TRACKER_DEFER", defer)
+        monkeypatch.setenv("VBT_TRACKER_STREAM", "inline")
+        pipe = Pipeline(model_path, n, max_frames=4 * T, fps=60.0, depth=depth)
+        assert pipe._defer == (depth if defer == "1" else 0) and pipe._ring == (2 * depth if defer == "1" else depth)
+        mid = None
+        for t in range(T):
+            if t in (5, 6, 13):
+                pipe.skip_frames(2)                                  # the frame stride changes inside / between groups
+            if t == 17:
+                # not a plain step (clip map + explicit frame numbers): flushes the group, runs per step
+                pipe.step(fd[t], st, clip_map=np.arange(n, dtype=np.int32), frame_idx=np.full(n, pipe.frame_count + 1))
+            else:
+                pipe.step(fd[t], st)
+            if t == 10:
+                mid = pipe.rows(0)                                   # a read in the middle drains the deferred steps first
+        best, n_rows, nph, ovf, ph = pipe.close(cap=16)
+        counts, rows = pipe.rows_all()
+        out[defer] = (best.copy(), n_rows.copy(), nph.copy(), ph.copy(), counts.copy(), [rows[c][:counts[c]].tobytes() for c in range(n)],
+                      {k: list(v) for k, v in mid.items()})
+    a, b = out["0"], out["1"]
+    for i in range(5):
+        assert np.array_equal(a[i], b[i])
+    assert int(a[1].sum()) > 10 * n
+    assert a[5] == b[5] and a[6] == b[6]
+
+
 def test_busy_streams_sit_on_distinct_hardware_queues(model_path):
     """Pipeline._place_streams: after creation every pair of the streams that carry kernels side by side (detector slots +
     the copy stream) runs two spinning waves concurrently; a stream against itself reads as shared (the probe's control)."""

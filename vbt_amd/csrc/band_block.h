@@ -312,7 +312,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #pragma unroll
         for (int m = 0; m < 3; m++) bv[u][m] = *(const v4i*)(pb[u] + tapoff[m]);
 #pragma unroll
-      for (int u = 0; u < U; u++) acc[u] = v4i_from(bq);
+      for (int u = 0; u < U; u++) acc[u] = v4i_from(int4_plus(bq, FULL >= 2 ? RQ_KBIAS : 0));
 #pragma unroll
       for (int m = 0; m < 3; m++)
 #pragma unroll
@@ -326,7 +326,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       for (; pg + nsub < NPG; pg += 2 * nsub) d_units(full_c, std::integral_constant<int, 2>{}, pg);
       if (pg < NPG) d_units(full_c, std::integral_constant<int, 1>{}, pg);
     };
-    if (a.rqd.full) d_walk(std::integral_constant<int, 1>{}); else d_walk(std::integral_constant<int, 0>{});
+    rq_dispatch(a.rqd, d_walk);
   }
   __syncthreads();
   BD_STAMP(2);
@@ -360,7 +360,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #pragma unroll
       for (int u = 0; u < U; u++) dv[u] = *(const v4i*)(D + ((pg0 + u * (nwaves / 4)) * 16 + r) * CS + 16 * g);
 #pragma unroll
-      for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, dv[u], v4i_from(bb), 0, 0, 0);
+      for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, dv[u], v4i_from(int4_plus(bb, FULL >= 2 ? RQ_KBIAS : 0)), 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int slot = (pg0 + u * (nwaves / 4)) * 16 + r;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       for (; pg + (nwaves / 4) < NPG; pg += 2 * (nwaves / 4)) p_units(full_c, std::integral_constant<int, 2>{}, pg);
       if (pg < NPG) p_units(full_c, std::integral_constant<int, 1>{}, pg);
     };
-    if (a.rqp.full) p_walk(std::integral_constant<int, 1>{}); else p_walk(std::integral_constant<int, 0>{});
+    rq_dispatch(a.rqp, p_walk);
   } else if (!C64 && NT <= nwaves && KS <= 2 && (nwaves - NT * (nwaves / NT)) * 8 <= nwaves) {   // (maps of more than 64 channels; at most an eighth of the waves without a tile)
     // any other width (Lite1 / Lite2 maps, the heads' 9- / 36-channel outputs): wave w owns output tile w % NT and, of the pixel groups,
     // every (NW / NT)-th one, so its weights / bias / multipliers are loop invariants held in registers (the unit loop below re-read

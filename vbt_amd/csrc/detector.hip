@@ -268,6 +268,26 @@ static void pack_weights64(const int8_t* w, int N, int K, int KS, int NB, std::v
         }
 }
 
+// Rq::kb (dev_common.h): the int32 accumulator of this conv, bias included, stays inside (-2^22, 2^22) for EVERY input.  Whatever way a
+// kernel folds the zero point into its bias, the value it requantises is sum_k (x_k - z_x) w_k + b with |x_k - z_x| <= 255, so
+// 255 * sum_k |w_k| + |b| bounds it per output channel.  VBT_NO_KBIAS: never (the kernels then convert with v_cvt_f32_i32).
+static int conv_kb(const vbt_model* m, const OpRec& op) {
+  static const bool off = getenv("VBT_NO_KBIAS") != nullptr;
+  if (off || (op.type != OP_STEM && op.type != OP_PW && op.type != OP_DW)) return 0;
+  const TensorRec& tin = m->tensors[op.inputs[0]];
+  const TensorRec& tout = m->tensors[op.output];
+  const int8_t* w = (const int8_t*)(m->blob.data() + op.w_off);
+  const int32_t* bq = (const int32_t*)(m->blob.data() + op.b_off);
+  const bool dw = op.type == OP_DW;
+  const int N = tout.c, K = dw ? op.k * op.k : op.k * op.k * tin.c;
+  for (int co = 0; co < N; co++) {
+    long long sa = 0;
+    for (int k = 0; k < K; k++) sa += std::abs((int)(dw ? w[(size_t)k * N + co] : w[(size_t)co * K + k]));
+    if (255 * sa + std::llabs((long long)bq[co]) >= (1ll << 22) - 1) return 0;
+  }
+  return 1;
+}
+
 // ---- fusion pass: MBConv (pw+relu6 -> dw -> pw [-> add]) and SeparableConv (dw -> pw) -> fused_block_kernel ----
 static void choose_tile(int OH, int OW, int KK, int S, bool expand, int* TXo, int* TYo, int slots = 64) {
   double best = 1e300;
@@ -318,7 +338,7 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     const OpRec& eop = m->ops[e_op];
     a.we = es.wp; a.be = es.bias; a.me = es.mult; a.KSe = es.KS;
     a.ze = tdin.zero_point; a.loe = eop.act_min; a.hie = eop.act_max;
-    a.rqe = make_rq(a.ze, a.loe, a.hie);
+    a.rqe = make_rq(a.ze, a.loe, a.hie, conv_kb(m, eop));
     // input tile rows hold the real channels (8-byte granules) + 8 bytes of bank spread, not the K padding of the expand
     // (KS * 32): the B-operand reads of the padded K steps run into the next pixel's bytes, which meet zero weights (the
     // last pixel's run into the E tile).  b1: 40 -> 24 bytes, b4 / b5: 72 -> 48 - LDS per workgroup sets the occupancy here.
@@ -399,7 +419,7 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
       a.wd64c = d64c;
     }
     a.zd = tdout.zero_point; a.lod = dop.act_min; a.hid = dop.act_max;
-    a.rqd = make_rq(a.zd, a.lod, a.hid);
+    a.rqd = make_rq(a.zd, a.lod, a.hid, conv_kb(m, dop));
   }
   // project weights re-packed with K padded to Cp
   {
@@ -630,8 +650,8 @@ static int make_band(vbt_model* m, int d_op, int p_op, int sum_op, const NodeSrc
   a.wd = dpd; a.wp = dpp; a.bd = dbd; a.md = dmd;
   a.bp = m->op_steps[p_op].bias;   // folded with the depthwise output's zero point, padded to 64
   a.mp = m->op_steps[p_op].mult;
-  a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max);
-  a.rqp = make_rq(to.zero_point, pop.act_min, pop.act_max);
+  a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max, conv_kb(m, dop));
+  a.rqp = make_rq(to.zero_point, pop.act_min, pop.act_max, conv_kb(m, pop));
   a.x = m->tptr[dop.inputs[0]];
   a.out = m->tptr[pop.output];
   std::vector<int> parts{d_op, p_op, sum_op};
@@ -832,9 +852,9 @@ static int make_stem_block(vbt_model* m, int si, Step* out) {
   a.tiles_x = (ts.w + 15) / 16; a.tiles_y = (ts.h + 15) / 16;
   a.in_pad4 = (unsigned)((ti.zero_point + 128) & 255) * 0x01010101u;
   a.zs4 = (unsigned)(ts.zero_point & 255) * 0x01010101u;
-  a.rqs = make_rq(ts.zero_point, st.act_min, st.act_max);
-  a.rqd = make_rq(td.zero_point, d.act_min, d.act_max);
-  a.rqp = make_rq(to.zero_point, p.act_min, p.act_max);
+  a.rqs = make_rq(ts.zero_point, st.act_min, st.act_max, conv_kb(m, st));
+  a.rqd = make_rq(td.zero_point, d.act_min, d.act_max, conv_kb(m, d));
+  a.rqp = make_rq(to.zero_point, p.act_min, p.act_max, conv_kb(m, p));
   int rc;
   {  // stem: K index 8kg + j -> kernel row kg, byte j of its 9 (kg < 3); (row j, byte 8) for kg == 3, j < 3
     const int8_t* w = (const int8_t*)(m->blob.data() + st.w_off);
@@ -1030,8 +1050,8 @@ static int make_expdw(vbt_model* m, int e_op, int d_op, Step* out) {
       (rc = upload(m, me, &dme)) || (rc = upload(m, md, &dmd)))
     return rc;
   a.we = dpe; a.wdc = dpd; a.be = dbe; a.bd = dbd; a.me = dme; a.md = dmd;
-  a.rqe = make_rq(te.zero_point, eop.act_min, eop.act_max);
-  a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max);
+  a.rqe = make_rq(te.zero_point, eop.act_min, eop.act_max, conv_kb(m, eop));
+  a.rqd = make_rq(td.zero_point, dop.act_min, dop.act_max, conv_kb(m, dop));
   a.zeb = (unsigned)(te.zero_point & 255) * 0x01010101u;
   s.lds_bytes = geo.t0_bytes + geo.e_bytes + geo.d_bytes;
   for (int oi : {e_op, d_op}) {

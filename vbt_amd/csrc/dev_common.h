@@ -27,9 +27,16 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
 struct Rq {
   float lo_f, hi_f, off;  // lo - zp, hi - zp, zp + 128
   int full;               // lo == -128 && hi == 127: the clamp is the [0,255] saturation of v_cvt_pk_u8_f32 itself
+  int kb;                 // every accumulator of this conv (bias included) lies in (-2^22, 2^22) - proven on the host from the weights
+                          // (conv_acc_bound): kernels may start their accumulators at bias + RQ_KBIAS and read them back as floats
 };
-__host__ __device__ inline Rq make_rq(int zp, int lo, int hi) {
-  return Rq{(float)(lo - zp), (float)(hi - zp), (float)(zp + 128), (lo <= -128 && hi >= 127) ? 1 : 0};
+// int -> float without v_cvt_f32_i32: for -2^22 <= acc < 2^22 the bit pattern 0x4B400000 + acc IS the float 1.5 * 2^23 + acc
+// (exponent of 2^23, mantissa 0x400000 + acc), and subtracting 1.5 * 2^23 is exact.  The MFMA accumulates on top of the initial
+// value, so a conv that starts at bias + RQ_KBIAS ends with that pattern for free; two v_pk_add_f32 then replace four
+// v_cvt_f32_i32 per dword of outputs (15 -> 13 vector instructions per four requantised elements, none of them VOP1).
+constexpr int RQ_KBIAS = 0x4B400000;
+__host__ __device__ inline Rq make_rq(int zp, int lo, int hi, int kb = 0) {
+  return Rq{(float)(lo - zp), (float)(hi - zp), (float)(zp + 128), (lo <= -128 && hi >= 127) ? 1 : 0, kb};
 }
 __device__ __forceinline__ float rq_u8(float accf, float mult, const Rq& q) {
   float r = __builtin_rintf(accf * mult);
@@ -45,12 +52,23 @@ __device__ __forceinline__ unsigned pack4_u8f(float a, float b, float c, float d
 // acc already contains the bias (accumulators are initialised with it).  The multiply and the offset add use the
 // packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32: two IEEE single ops per instruction, same results).
 typedef float v2f __attribute__((ext_vector_type(2)));
+// FULLK: -1 = the clamp flavour is read from q.full at run time; otherwise bit 0 = saturating flavour (q.full), bit 1 = the
+// accumulators were started at bias + RQ_KBIAS (q.kb; the caller adds it where it loads the bias)
 template <int FULLK = -1>
 __device__ __forceinline__ unsigned rq_pack_b(const v4i& acc, const float4& mu, const Rq& q) {
-  v2f t0 = (v2f){(float)acc[0], (float)acc[1]} * (v2f){mu.x, mu.y};
-  v2f t1 = (v2f){(float)acc[2], (float)acc[3]} * (v2f){mu.z, mu.w};
+  v2f f0, f1;
+  if (FULLK >= 2) {
+    const v2f kf = {12582912.0f, 12582912.0f};
+    f0 = (v2f){__int_as_float(acc[0]), __int_as_float(acc[1])} - kf;
+    f1 = (v2f){__int_as_float(acc[2]), __int_as_float(acc[3])} - kf;
+  } else {
+    f0 = (v2f){(float)acc[0], (float)acc[1]};
+    f1 = (v2f){(float)acc[2], (float)acc[3]};
+  }
+  v2f t0 = f0 * (v2f){mu.x, mu.y};
+  v2f t1 = f1 * (v2f){mu.z, mu.w};
   const v2f off = {q.off, q.off};
-  if (FULLK == 1 || (FULLK < 0 && q.full)) {
+  if ((FULLK >= 0 && (FULLK & 1)) || (FULLK < 0 && q.full)) {
     // rne(t) by the float adder: t + 1.5*2^23 has ulp 1 and an even base, so the sum is exactly 1.5*2^23 + rne(t) for
     // |t| < 2^22; adding (zp + 128 - 1.5*2^23) is exact again and the u8 conversion saturates to [0, 255], which IS the
     // clamp to int8 (+128).  |t| >= 2^22 stays far outside [0, 255] on the same side, i.e. saturates like the clamp.
@@ -82,6 +100,13 @@ __device__ __forceinline__ int fdiv_small(int n, float rcp_d) { return (int)(((f
 // 0.5 / d away from an integer and the product carries < 2^-22 relative error, so the floor is exact for n < 2^20.
 __device__ __forceinline__ float frcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
 __device__ __forceinline__ v4i v4i_from(const int4& b) { return (v4i){b.x, b.y, b.z, b.w}; }
+__device__ __forceinline__ int4 int4_plus(const int4& b, int k) { return make_int4(b.x + k, b.y + k, b.z + k, b.w + k); }
+// run f(std::integral_constant<int, mode>) with mode = q.full | q.kb << 1 (uniform: one of four instantiations of a stage)
+template <class F>
+__device__ __forceinline__ void rq_dispatch(const Rq& q, F&& f) {
+  if (q.kb) { if (q.full) f(std::integral_constant<int, 3>{}); else f(std::integral_constant<int, 2>{}); }
+  else { if (q.full) f(std::integral_constant<int, 1>{}); else f(std::integral_constant<int, 0>{}); }
+}
 
 __device__ __forceinline__ unsigned rq_pack_i(const v4i& acc, const int4& b, const float4& mu, const Rq& q) {
   const v4i a2 = {acc[0] + b.x, acc[1] + b.y, acc[2] + b.z, acc[3] + b.w};

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
           v4i ew[KS64];
 #pragma unroll
           for (int ks = 0; ks < KS64; ks++) ew[ks] = *(const v4i*)(Pe + 16 * ((ks * 4 + 2 * tp + tt) * 64 + lane));
-          const int4 eb = *(const int4*)(Pe + 16 * (KS64 * 256) + 4 * (16 * (2 * tp + tt) + 4 * g));
+          const int4 eb = int4_plus(*(const int4*)(Pe + 16 * (KS64 * 256) + 4 * (16 * (2 * tp + tt) + 4 * g)), FULL >= 2 ? RQ_KBIAS : 0);
           const float4 em = *(const float4*)(Pe + 16 * (KS64 * 256 + 16) + 4 * (16 * (2 * tp + tt) + 4 * g));
           v4i acc[GPW];
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
           }
         }
       };
-      if (a.rqe.full) e_stage(std::integral_constant<int, 1>{}); else e_stage(std::integral_constant<int, 0>{});
+      rq_dispatch(a.rqe, e_stage);
     }
     __syncthreads();   // E complete, D free
     XD2_STAMP(2 + 2 * (c - c_first));
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-          for (int q = 0; q < QW; q++) acc[u][q] = v4i_from(bq[q]);
+          for (int q = 0; q < QW; q++) acc[u][q] = v4i_from(int4_plus(bq[q], FULL >= 2 ? RQ_KBIAS : 0));
 #pragma unroll
         for (int mi = 0; mi < KT2; mi++)
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NW) void expdw2_kernel(ExpDw2Args a) {
       auto d_walk = [&](auto full_c) {   // position groups in pairs (two groups x QW quads: independent MFMA chains), unrolled: register-indexed offsets
         d_pair<0>(d_units, full_c, NPGo);
       };
-      if (a.rqd.full) d_walk(std::integral_constant<int, 1>{}); else d_walk(std::integral_constant<int, 0>{});
+      rq_dispatch(a.rqd, d_walk);
     }
     put_pe();
     __syncthreads();   // D complete, E free for the next chunk's expand, its expand parameters in Pe

@@ -339,12 +339,15 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       // loop body stays one basic block and the scheduler can overlap the four MFMAs with the previous tile's epilogue
       auto expand_loop = [&](auto full_tag) {
         constexpr int FULLK = decltype(full_tag)::value;
+        int4 ebk[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) ebk[t] = int4_plus(eb[t], FULLK >= 2 ? RQ_KBIAS : 0);
         for (int i = 0, pg = wave; pg < NPG; pg += 4, i++) {
           const int p = pg * 16 + r;
           const int pc = min(p, NPh - 1);
           v4i ea[NT];
 #pragma unroll
-          for (int t = 0; t < NT; t++) ea[t] = v4i_from(eb[t]);
+          for (int t = 0; t < NT; t++) ea[t] = v4i_from(ebk[t]);
           const unsigned char* brow = T0 + pc * a.T0S + 8 * g;
           if constexpr (KSE > 0) {
 #pragma unroll
@@ -377,8 +380,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
           }
         }
       };
-      if (a.rqe.full) expand_loop(std::integral_constant<int, 1>{});
-      else expand_loop(std::integral_constant<int, 0>{});
+      rq_dispatch(a.rqe, expand_loop);
       __syncthreads();
     }
     // ---- stage D: depthwise on chunk c ----
@@ -391,26 +393,31 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
         v4i wreg[KT64];
 #pragma unroll
         for (int mi = 0; mi < KT64; mi++) wreg[mi] = diag_operand((unsigned)(wc >> (8 * mi)) & 0xffu, r);
-        const int4 bqm = *(const int4*)(a.bdm + c * CH + 16 * wave + 4 * g);
+        const int4 bq0 = *(const int4*)(a.bdm + c * CH + 16 * wave + 4 * g);
         const float4 mum = *(const float4*)(a.md + c * CH + 16 * wave + 4 * g);
         const int hb = TXP == 8 ? ((r >> 3) * S * HWX + (r & 7) * S) : r * S;   // window origin of slot r of group 0
         const unsigned char* baseH = E + hb * EST + 16 * wave + g * EST;          // g = column of the tap
         const unsigned char* baseV = E + hb * EST + 16 * wave + g * (HWX * EST);  // g = row of the tap (5x5, column 4)
+        auto dw_walk = [&](auto mode_tag) {
+          constexpr int RM = decltype(mode_tag)::value;
+          const int4 bqm = int4_plus(bq0, RM >= 2 ? RQ_KBIAS : 0);
 #pragma unroll
-        for (int pg = 0; pg < 4 * PPW; pg += 2) {   // two slot groups at a time: independent accumulate chains
-          v4i dqa = v4i_from(bqm), dqb = v4i_from(bqm);
+          for (int pg = 0; pg < 4 * PPW; pg += 2) {   // two slot groups at a time: independent accumulate chains
+            v4i dqa = v4i_from(bqm), dqb = v4i_from(bqm);
 #pragma unroll
-          for (int mi = 0; mi < KT64; mi++) {
-            const unsigned char* bp = (KK == 5 && mi == 5) ? baseV : baseH;
-            const int off = KK == 3 ? mi * HWX * EST : (mi < 5 ? mi * HWX * EST : (mi == 5 ? 4 * EST : (4 * HWX + 4) * EST));
-            const v4i bva = *(const v4i*)(bp + pg * PGS + off);
-            const v4i bvb = *(const v4i*)(bp + (pg + 1) * PGS + off);
-            dqa = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], bva, dqa, 0, 0, 0);
-            dqb = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], bvb, dqb, 0, 0, 0);
+            for (int mi = 0; mi < KT64; mi++) {
+              const unsigned char* bp = (KK == 5 && mi == 5) ? baseV : baseH;
+              const int off = KK == 3 ? mi * HWX * EST : (mi < 5 ? mi * HWX * EST : (mi == 5 ? 4 * EST : (4 * HWX + 4) * EST));
+              const v4i bva = *(const v4i*)(bp + pg * PGS + off);
+              const v4i bvb = *(const v4i*)(bp + (pg + 1) * PGS + off);
+              dqa = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], bva, dqa, 0, 0, 0);
+              dqb = __builtin_amdgcn_mfma_i32_16x16x64_i8(wreg[mi], bvb, dqb, 0, 0, 0);
+            }
+            *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b<RM>(dqa, mum, a.rqd);
+            *(unsigned*)(D + ((pg + 1) * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b<RM>(dqb, mum, a.rqd);
           }
-          *(unsigned*)(D + (pg * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dqa, mum, a.rqd);
-          *(unsigned*)(D + ((pg + 1) * 16 + r) * FB_DST + 16 * wave + 4 * g) = rq_pack_b(dqb, mum, a.rqd);
-        }
+        };
+        rq_dispatch(a.rqd, dw_walk);
       }
     } else if constexpr (MDW) {
       // Matrix-pipe depthwise: out[c][p] = sum_t W'[c][(t,c')] * X[(t,c')][p] with W' = w[t][c] * delta(c,c').

@@ -98,8 +98,9 @@ int launch_expdw2(const ExpDw2Args& a, int k, int stride, int KS64, int nw, int 
 }
 
 int launch_stem_block(const StemBlockArgs& a, bool full_range, unsigned grid, hipStream_t st) {
-  if (full_range) stem_block_kernel<true><<<dim3(grid), 256, 0, st>>>(a);
-  else stem_block_kernel<false><<<dim3(grid), 256, 0, st>>>(a);
+  if (full_range && a.rqs.kb && a.rqd.kb && a.rqp.kb) stem_block_kernel<3><<<dim3(grid), 256, 0, st>>>(a);
+  else if (full_range) stem_block_kernel<1><<<dim3(grid), 256, 0, st>>>(a);
+  else stem_block_kernel<0><<<dim3(grid), 256, 0, st>>>(a);
   return VBT_OK;
 }
 

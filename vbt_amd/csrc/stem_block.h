@@ -40,10 +40,12 @@ struct StemBlockArgs {
 constexpr int SB_HW = 18, SB_NPH = SB_HW * SB_HW, SB_NPG = (SB_NPH + 15) / 16;
 constexpr int SB_RROWS = 37, SB_RDW = 30, SB_RST = SB_RDW * 4, SB_PST = 32, SB_SST = 48, SB_DST = 40;
 
-// FULL: all three requantisations clamp at the int8 limits (the saturating flavour, no per-element branch)
-template <bool FULL>
+// MODE 1: all three requantisations clamp at the int8 limits (the saturating flavour, no per-element branch); MODE 3: and all
+// three convs' accumulators are proven to stay inside +-2^22 (Rq::kb: accumulators start at bias + RQ_KBIAS); MODE 0: read at run time
+template <int MODE>
 __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
-  constexpr int FK = FULL ? 1 : -1;
+  constexpr int FK = MODE == 0 ? -1 : MODE;
+  constexpr int KB = MODE >= 2 ? RQ_KBIAS : 0;
   // R is dead once P is built and P once S is built: R shares S's storage, D shares P's (23.8 KB -> 6 workgroups / CU)
   __shared__ __attribute__((aligned(16))) unsigned char SR[SB_NPH * SB_SST + 64];
   __shared__ __attribute__((aligned(16))) unsigned char PD[SB_NPG * 16 * SB_PST];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
   // ---- 2: stem conv on the 18x18 halo, 2 MFMAs per 16 pixels (32 output channels) ----
   {
     const long wa0 = a.ws[lane], wa1 = a.ws[64 + lane];
-    const int4 b0 = *(const int4*)(a.bs + 8 * g), b1 = *(const int4*)(a.bs + 8 * g + 4);
+    const int4 b0 = int4_plus(*(const int4*)(a.bs + 8 * g), KB), b1 = int4_plus(*(const int4*)(a.bs + 8 * g + 4), KB);
     const float4 m0 = *(const float4*)(a.ms + 8 * g), m1 = *(const float4*)(a.ms + 8 * g + 4);
     // halo pixels outside the stem's output map (tiles on the map border only): bit i <-> pixel group wave + 4i
     unsigned oob_mask = 0;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
     v4i wreg[3];
 #pragma unroll
     for (int mi = 0; mi < 3; mi++) wreg[mi] = a.wd64[(cg * 3 + mi) * 64 + lane];
-    const int4 bqm = *(const int4*)(a.bdm + 16 * cg + 4 * g);
+    const int4 bqm = int4_plus(*(const int4*)(a.bdm + 16 * cg + 4 * g), KB);
     const float4 mum = *(const float4*)(a.mdm + 16 * cg + 4 * g);
     // lane (r = output column, g = tap column): B operand of instruction m for output row py = 16 channels of halo pixel
     // (py + m, r + g); g = 3 carries zero weights (it reads one pixel past the window: still inside S)
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void stem_block_kernel(StemBlockArgs a) {
   // ---- 4: project 32 -> Cout (<= 16): one MFMA per 16 pixels, lane -> 4 consecutive channels of pixel r ----
   {
     const long wa = a.wp[lane];
-    const int4 bb = *(const int4*)(a.bp + 4 * g);
+    const int4 bb = int4_plus(*(const int4*)(a.bp + 4 * g), KB);
     const float4 mm = *(const float4*)(a.mp + 4 * g);
 #pragma unroll
     for (int i = 0; i < 4; i++) {

@@ -149,11 +149,24 @@ class Pipeline:
         self.frame_count = 0                        # time counter of the clips: time = frame_count / fps (track.py:161,169)
         self._step_idx = 0                          # steps enqueued so far: selects the ring slot, independent of time
         n = self.n
-        self._bufs = [(torch.empty((n, 25, 4), dtype=torch.float32, device=tdev), torch.empty((n, 25), dtype=torch.float32, device=tdev),
-                       torch.empty((n, 25), dtype=torch.float32, device=tdev), torch.empty((n,), dtype=torch.int32, device=tdev))
-                      for _ in range(self.depth)]
-        self._times = [np.zeros(n, np.float64) for _ in range(self.depth)]
-        self._maps = [None] * self.depth             # per-slot clip maps of the steps in flight
+        # Deferred tracker steps (small batches): a forward of <= 8 frames is a chain of launch-latency-sized kernels, and one
+        # single-wave tracker launch plus its cross-stream event at the end of EVERY forward costs a fifth of the step (batch 1,
+        # depth 4: 147 vs 121 us per step).  With deferral the detections of `depth` consecutive steps stay in a ring of output
+        # slots and ONE launch of the time-batched walk (vbt_tracker_update_from_detections_seq: one wavefront per clip steps
+        # through the group in frame order) follows the group's last forward.  Rows, ids and phases are those of the per-step
+        # form (same kernel code per frame); only plain steps (no clip_map / active) are deferred.
+        dflt = "1" if (self.n <= 8 and self.n_trk == self.n and self.depth >= 2) else "0"
+        inline = os.environ.get("VBT_TRACKER_STREAM", "inline" if self.depth >= 3 else "own") == "inline"
+        self._defer = self.depth if os.environ.get("VBT_TRACKER_DEFER", dflt) == "1" and self.n_trk == self.n and self.depth >= 2 and inline else 0
+        self._ring = R = 2 * self.depth if self._defer else self.depth     # output slots: a group may still be read while the next one fills
+        # one block per output tensor, [ring slot][clip]...: the walk addresses frame f of clip c as slot (o0 + f) * n + c
+        self._out = (torch.empty((R, n, 25, 4), dtype=torch.float32, device=tdev), torch.empty((R, n, 25), dtype=torch.float32, device=tdev),
+                     torch.empty((R, n, 25), dtype=torch.float32, device=tdev), torch.empty((R, n), dtype=torch.int32, device=tdev))
+        self._bufs = [tuple(t[o] for t in self._out) for o in range(R)]
+        self._times = [np.zeros(n, np.float64) for _ in range(R)]
+        self._maps = [None] * R                      # per-slot clip maps of the steps in flight
+        self._fc = [0] * R                           # per-slot frame number of a plain step
+        self._group = []                             # deferred plain steps (output slots, ascending), not yet handed to the tracker
         # The pipeline's own HIP streams, created back to back (detector slots, tracker, copy): each is bound to its
         # hardware queue at creation (vbt_stream_create), so they sit on distinct queues.  Streams from torch's pool may have
         # been used before and then share a queue with a neighbour - measured 89 k -> 58 k frames/s.
@@ -174,8 +187,8 @@ class Pipeline:
         self._place_streams(tdev)
         self._last_trk_ev = None                    # the most recent tracker step (inline mode orders the steps through it)
         self._ev_in = [torch.cuda.Event() for _ in range(self.depth)]
-        self._ev_det = [torch.cuda.Event() for _ in range(self.depth)]
-        self._ev_trk = [None] * self.depth          # tracker finished reading slot k's outputs
+        self._ev_det = [torch.cuda.Event() for _ in range(self._ring)]
+        self._ev_trk = [None] * self._ring          # tracker finished reading output slot o
         self._pending = []                          # slots whose tracker step has not been enqueued yet
         self._resized = [None] * self.depth         # per-slot network-resolution frames (source-resolution input)
         # step() on pinned host memory: H2D copies run on their own stream into a ring of depth + 2 staging buffers, i.e. up
@@ -323,14 +336,15 @@ class Pipeline:
         except Exception:
             pass
 
-    def _enqueue_tracker(self, k):
+    def _enqueue_tracker(self, o):
         if self._trk_inline:
-            T = self._det_streams[k]                                 # stream order gives "after this slot's detections"
+            T = self._det_streams[o % self.depth]                    # stream order gives "after this slot's detections"
             if self._last_trk_ev is not None:
                 T.wait_event(self._last_trk_ev)                      # tracker steps run in frame order
         else:
             T = self._trk_stream
-            T.wait_event(self._ev_det[k])
+            T.wait_event(self._ev_det[o])
+        k = o
         b, s, c, cnt = self._bufs[k]
         # frame times / clip map of the step travel in the kernel arguments (read during the call, no copy in flight)
         tm = self._times[k]
@@ -350,6 +364,36 @@ class Pipeline:
         self._ev_trk[k] = ev
         self._last_trk_ev = ev
 
+    def _flush_group(self):
+        """Hand the deferred plain steps to the tracker: ONE launch of the time-batched walk on the stream of the group's last
+        forward, after the other members' forwards (events) and the previous tracker launch."""
+        g, self._group = self._group, []
+        if not g:
+            return
+        for o in g:
+            self._pending.remove(o)
+        if len(g) == 1:
+            self._enqueue_tracker(g[0])
+            return
+        n, last = self.n, g[-1]
+        T = self._det_streams[last % self.depth]
+        for o in g[:-1]:
+            T.wait_event(self._ev_det[o])
+        if self._last_trk_ev is not None:
+            T.wait_event(self._last_trk_ev)
+        fstep = self._fc[g[1]] - self._fc[g[0]]
+        ra = (_lib.Run * n)()
+        for c in range(n):
+            ra[c] = _lib.Run(c, c, n, len(g), self._fc[g[0]], fstep, float(self.fps[c]))
+        b, s, _, cnt = self._bufs[g[0]]                              # slot (o - g[0]) * n + c of the block that starts here
+        _lib.check(_lib.lib().vbt_tracker_update_from_detections_seq(self.tracker.handle, b.data_ptr(), s.data_ptr(), cnt.data_ptr(), len(g) * n,
+                                                                     ra, n, self.thr, T.cuda_stream))
+        ev = self._torch.cuda.Event()
+        ev.record(T)
+        for o in g:
+            self._ev_trk[o] = ev
+        self._last_trk_ev = ev
+
     def step(self, frames_dev_ptr, stream=None, src_hw=None, swap_rb=False, active=None, clip_map=None, frame_idx=None, track=True):
         """frames_dev_ptr: uint8 [n,H,W,3] on the device (frame `frame_count+1` of every clip), valid on the caller's current
         torch stream: either a torch tensor (preferred: its lifetime is then handled here) or a raw device pointer, which
@@ -363,9 +407,14 @@ class Pipeline:
         empty slot).  With tracker_clips > n_clips a slot moves on to the next clip of its queue when one ends, so a corpus
         of ragged clips keeps the whole detector batch busy."""
         torch = self._torch
-        k = self._step_idx % self.depth
-        if k in self._pending:
-            raise RuntimeError(f"Pipeline: ring slot {k} still holds a step whose tracker update has not been enqueued")
+        o = self._step_idx % self._ring                              # output slot; k = forward slot (model instance, stream)
+        k = o % self.depth
+        plain = clip_map is None and active is None and track
+        if self._group and (not plain or o <= self._group[-1] or
+                            (len(self._group) >= 2 and self.frame_count + 1 - self._fc[self._group[-1]] != self._fc[self._group[1]] - self._fc[self._group[0]])):
+            self._flush_group()                                      # (ring wrap, another kind of step, or skip_frames() changed the frame stride)
+        if o in self._pending:
+            raise RuntimeError(f"Pipeline: ring slot {o} still holds a step whose tracker update has not been enqueued")
         self._step_idx += 1
         self.frame_count += 1
         S = self._det_streams[k]
@@ -383,8 +432,8 @@ class Pipeline:
                 frames_dev_ptr = frames_dev_ptr.data_ptr()
         self._ev_in[k].record(torch.cuda.current_stream())           # frames are ready once the caller's stream gets here
         S.wait_event(self._ev_in[k])
-        if self._ev_trk[k] is not None:
-            S.wait_event(self._ev_trk[k])                            # the tracker is done with this slot's previous outputs
+        if self._ev_trk[o] is not None:
+            S.wait_event(self._ev_trk[o])                            # the tracker is done with this slot's previous outputs
         stage_j = None
         if host_frames is not None:
             stage_j = j = self._stage_idx % len(self._stage)
@@ -407,31 +456,37 @@ class Pipeline:
             _lib.check(_lib.lib().vbt_resize_frames(frames_dev_ptr, self.n, int(src_hw[0]), int(src_hw[1]), 1, self._resized[k].data_ptr(),
                                                     size, size, 1, int(bool(swap_rb)), self._dev, S.cuda_stream))
             frames_dev_ptr = self._resized[k].data_ptr()
-        self._maps[k] = None
+        self._maps[o] = None
+        self._fc[o] = self.frame_count
         if clip_map is not None:
             cm = np.ascontiguousarray(clip_map, dtype=np.int32)
             fi = np.asarray(frame_idx, np.float64)
-            self._maps[k] = cm
-            self._times[k][:] = np.where(cm >= 0, fi / self.fps[np.maximum(cm, 0)], -1.0)
+            self._maps[o] = cm
+            self._times[o][:] = np.where(cm >= 0, fi / self.fps[np.maximum(cm, 0)], -1.0)
         elif active is None:
-            np.divide(float(self.frame_count), self.fps, out=self._times[k])  # time = frame_count / fps (track.py:169)
+            np.divide(float(self.frame_count), self.fps, out=self._times[o])  # time = frame_count / fps (track.py:169)
         else:
             act = np.asarray(active, bool)
             self._clip_frames = getattr(self, "_clip_frames", np.zeros(self.n, np.int64))
             self._clip_frames[act] += 1
-            np.divide(self._clip_frames.astype(np.float64), self.fps, out=self._times[k])
-            self._times[k][~act] = -1.0
-        b, s, c, cnt = self._bufs[k]
+            np.divide(self._clip_frames.astype(np.float64), self.fps, out=self._times[o])
+            self._times[o][~act] = -1.0
+        b, s, c, cnt = self._bufs[o]
         _lib.check(_lib.lib().vbt_detect_async(self.interpreters[k].handle, frames_dev_ptr, self.n, S.cuda_stream, b.data_ptr(),
                                                s.data_ptr(), c.data_ptr(), cnt.data_ptr()))
-        self._ev_det[k].record(S)
+        self._ev_det[o].record(S)
         if stage_j is not None:
             ev = torch.cuda.Event()
             ev.record(S)
             self._stage_free[stage_j] = ev
         if not track:                                                # detector-only step (measurement splits)
             return
-        self._pending.append(k)
+        self._pending.append(o)
+        if self._defer and plain:
+            self._group.append(o)
+            if len(self._group) >= self._defer or o % self._defer == self._defer - 1:    # groups are aligned: their slots never wrap
+                self._flush_group()
+            return
         # own stream: keep depth-1 detector steps ahead of the tracker; inline: the step follows its forward directly
         while len(self._pending) >= (1 if self._trk_inline else self.depth):
             self._enqueue_tracker(self._pending.pop(0))
@@ -465,9 +520,11 @@ class Pipeline:
         L = _lib.lib()
         if outputs is not None and track:
             raise ValueError("step_runs: outputs= is for detector-only steps (track=False)")
-        k = self._step_idx % self.depth
-        if k in self._pending:
-            raise RuntimeError(f"Pipeline: ring slot {k} still holds a step whose tracker update has not been enqueued")
+        self._flush_group()
+        o = self._step_idx % self._ring
+        k = o % self.depth
+        if o in self._pending:
+            raise RuntimeError(f"Pipeline: ring slot {o} still holds a step whose tracker update has not been enqueued")
         ra = (_lib.Run * len(runs))()
         B = 0
         for i, r in enumerate(runs):
@@ -481,8 +538,8 @@ class Pipeline:
         S = self._det_streams[k]
         self._ev_in[k].record(torch.cuda.current_stream())
         S.wait_event(self._ev_in[k])
-        if self._ev_trk[k] is not None:
-            S.wait_event(self._ev_trk[k])
+        if self._ev_trk[o] is not None:
+            S.wait_event(self._ev_trk[o])
         size = int(self.interpreter.get_input_details()[0]["shape"][1])
         stage_j = None
         if isinstance(frames, (list, tuple)):
@@ -565,7 +622,7 @@ class Pipeline:
             _lib.check(L.vbt_resize_frames(frames_ptr, B, int(src_hw[0]), int(src_hw[1]), 1, self._resized[k].data_ptr(), size, size, 1,
                                            int(bool(swap_rb)), self._dev, S.cuda_stream))
             frames_ptr = self._resized[k].data_ptr()
-        b, s_, c, cnt = self._bufs[k] if outputs is None else outputs
+        b, s_, c, cnt = self._bufs[o] if outputs is None else outputs
         if outputs is not None:
             for t_, shp_, dt_ in zip(outputs, ((B, 25, 4), (B, 25), (B, 25), (B,)), (torch.float32, torch.float32, torch.float32, torch.int32)):
                 if tuple(t_.shape) != shp_ or t_.dtype != dt_ or not t_.is_contiguous() or t_.device.type != "cuda":
@@ -573,16 +630,16 @@ class Pipeline:
                 t_.record_stream(S)
         _lib.check(L.vbt_detect_async(self.interpreters[k].handle, frames_ptr, B, S.cuda_stream, b.data_ptr(), s_.data_ptr(), c.data_ptr(),
                                       cnt.data_ptr()))
-        self._ev_det[k].record(S)
+        self._ev_det[o].record(S)
         if stage_j is not None:
             ev = torch.cuda.Event()
             ev.record(S)
             self._stage_free[stage_j] = ev
-        self._maps[k] = ("runs", ra, B)
+        self._maps[o] = ("runs", ra, B)
         self._last_B = B
         if not track:
             return
-        self._pending.append(k)
+        self._pending.append(o)
         while len(self._pending) >= (1 if self._trk_inline else self.depth):
             self._enqueue_tracker(self._pending.pop(0))
 
@@ -610,7 +667,7 @@ class Pipeline:
         self.tracker.reset()
         self.frame_count = 0
         self._step_idx = 0
-        self._ev_trk = [None] * self.depth
+        self._ev_trk = [None] * self._ring
         self._last_trk_ev = None
         if hasattr(self, "_clip_frames"):
             self._clip_frames[:] = 0
@@ -641,6 +698,7 @@ class Pipeline:
         self.frame_count += int(n)
 
     def _drain(self):
+        self._flush_group()
         while self._pending:
             self._enqueue_tracker(self._pending.pop(0))
         if self._trk_inline and self._last_trk_ev is not None:       # clip close / row reads run on the tracker stream
@@ -674,7 +732,7 @@ class Pipeline:
 
     def detections(self):
         """Most recent step's detector outputs (host copies) - for tests."""
-        k = (self._step_idx - 1) % self.depth
-        self._det_streams[k].synchronize()
-        b, s, c, cnt = self._bufs[k]
+        o = (self._step_idx - 1) % self._ring
+        self._det_streams[o % self.depth].synchronize()
+        b, s, c, cnt = self._bufs[o]
         return b.cpu().numpy(), s.cpu().numpy(), c.cpu().numpy(), cnt.cpu().numpy()
