@@ -980,7 +980,7 @@ __global__ __launch_bounds__(64) void tracker_seq_kernel(ClipState* states, Row*
   if (r.clip < 0) return;
   ClipState* gst = &states[r.clip];
   ClipState* st = gst;
-  const bool cached = lds_state != 0 && r.n_frames >= SEQ_LDS_MIN;
+  const bool cached = lds_state != 0 && r.n_frames >= lds_state;   // lds_state = shortest run that is worth the copy in and out
   if (cached) {
     ClipState* lst = (ClipState*)seq_dyn;
     copy_words(lst, gst, (int)offsetof(ClipState, trk), lane);
@@ -1474,7 +1474,8 @@ int vbt_tracker_update_from_detections_seq(vbt_tracker* t, const float* boxes_de
     int longest = 0;
     for (int i = 0; i < nb; i++) longest = std::max(longest, meta.run[i].clip >= 0 ? meta.run[i].n_frames : 0);
     static const bool lds_off = getenv("VBT_SEQ_NO_LDS") != nullptr;
-    int lds_state = (longest >= SEQ_LDS_MIN && !lds_off) ? 1 : 0;
+    static const int lds_min = getenv("VBT_SEQ_LDS_MIN") ? std::max(1, atoi(getenv("VBT_SEQ_LDS_MIN"))) : SEQ_LDS_MIN;
+    int lds_state = (longest >= lds_min && !lds_off) ? lds_min : 0;
     if (lds_state) {
       // opt in to the dynamic LDS of the cached state once per device; if the runtime refuses, the walk works on global memory
       static int attr_state[64] = {0};   // per device: 0 = not tried, 1 = granted, -1 = refused
