@@ -81,7 +81,7 @@ def test_lite2_batch64_equals_oracle_with_the_pinned_plan(oracle_lib):
     """BASELINE config 4 at its bench shape: 64 frames of 448x448 in one forward of the committed Lite2 container under the
     plan bench.py pins (profiles/plan_lite2.b64.f0: row-band expand + depthwise on b11-b19, row-band BiFPN nodes / head layers
     of width 112) - boxes, scores and counts of every frame equal the oracle's, and a second pass through the depth-3
-    pipeline with OC-SORT gives the oracle chain's rows for four of the clips."""
+    pipeline with OC-SORT gives the oracle chain's rows for four of the clips.  16 steps of 64 frames (1024 Lite2 frames on the oracle: ~20 s on 16 cores)."""
     import torch
     from oracle import ocsort_np
     from vbt_amd import synth
@@ -90,7 +90,7 @@ def test_lite2_batch64_equals_oracle_with_the_pinned_plan(oracle_lib):
     old = os.environ.get("VBT_PLAN_FILE")
     os.environ["VBT_PLAN_FILE"] = os.path.join(ROOT, "profiles", "plan_lite2")
     try:
-        n, T, S = 64, 3, 448
+        n, T, S = 64, 16, 448                      # 16 steps: the tracker is past min_hits on every clip, the ring of the pipeline wraps five times
         frames = np.stack([np.stack([synth.render(synth.background(300 + c, S), 5 * c + 2 * t) for c in range(n)]) for t in range(T)])
         pipe = Pipeline(model, n, max_frames=T, fps=30.0, rows_per_frame=25)
     finally:

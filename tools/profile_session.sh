@@ -31,6 +31,12 @@ session() {   # $1 = output prefix ("" | lite2_), environment selects model and 
   echo "${PRE}counters done"
 }
 session ""
+# what a small-batch forward is made of: kernel duration and gap per launch position, one stream, hipGraph replay
+for nb in 1 8; do
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_b$nb -o t -- python3 tools/b1_trace.py run $nb > $OUT/tr_b$nb.log 2>&1
+  python3 tools/b1_trace.py parse $OUT/tr_b$nb > $OUT/b${nb}_trace.txt 2>&1
+done
+echo "small-batch traces done"
 # BASELINE config 4: EfficientDet-Lite2 448x448 through the same contract run (rehearsal knob VBT_BENCH_MODEL), its own pinned plan
 export VBT_BENCH_MODEL=$PWD/models/efficientdet_lite2_synth.vbtm
 export VBT_PLAN_FILE=$PWD/profiles/plan_lite2
