@@ -253,7 +253,7 @@ static void pack_weights(const int8_t* w, int N, int K, int KS, int NB, const st
 
 // 16x16x64 layout: [(nb*KS + ks)*4 + t][lane][16 bytes]; lane (i = lane&15, g = lane>>4) holds
 // W[cout = 64nb + 16(i>>2) + 4t + (i&3)][k = 64ks + 16g + j], zero beyond N / K.
-static void pack_weights64(const int8_t* w, int N, int K, int KS, int NB, std::vector<v4i>& out) {
+static void pack_weights64(const int8_t* w, int N, int K, int KS, int NB, std::vector<v4i>& out, const std::vector<int>* kmap = nullptr) {
   out.assign((size_t)NB * KS * 4 * 64, (v4i){0, 0, 0, 0});
   int8_t* o = (int8_t*)out.data();
   for (int nb = 0; nb < NB; nb++)
@@ -262,8 +262,9 @@ static void pack_weights64(const int8_t* w, int N, int K, int KS, int NB, std::v
         for (int lane = 0; lane < 64; lane++) {
           const int i = lane & 15, g = lane >> 4, co = 64 * nb + 16 * (i >> 2) + 4 * t + (i & 3);
           for (int j = 0; j < 16; j++) {
-            const int k = 64 * ks + 16 * g + j;
-            o[((((size_t)(nb * KS + ks) * 4 + t) * 64 + lane) * 16) + j] = (co < N && k < K) ? w[(size_t)co * K + k] : 0;
+            const int kp = 64 * ks + 16 * g + j;
+            const int k = kmap ? (kp < (int)kmap->size() ? (*kmap)[kp] : -1) : (kp < K ? kp : -1);
+            o[((((size_t)(nb * KS + ks) * 4 + t) * 64 + lane) * 16) + j] = (co < N && k >= 0) ? w[(size_t)co * K + k] : 0;
           }
         }
 }
@@ -272,7 +273,7 @@ static void pack_weights64(const int8_t* w, int N, int K, int KS, int NB, std::v
 // kernel folds the zero point into its bias, the value it requantises is sum_k (x_k - z_x) w_k + b with |x_k - z_x| <= 255, so
 // 255 * sum_k |w_k| + |b| bounds it per output channel.  VBT_NO_KBIAS: never (the kernels then convert with v_cvt_f32_i32).
 static int conv_kb(const vbt_model* m, const OpRec& op) {
-  static const bool off = getenv("VBT_NO_KBIAS") != nullptr;
+  const bool off = getenv("VBT_NO_KBIAS") != nullptr;   // (read per model: tests build both flavours in one process)
   if (off || (op.type != OP_STEM && op.type != OP_PW && op.type != OP_DW)) return 0;
   const TensorRec& tin = m->tensors[op.inputs[0]];
   const TensorRec& tout = m->tensors[op.output];
@@ -424,15 +425,15 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
   // project weights re-packed with K padded to Cp
   {
     const int8_t* w = (const int8_t*)(m->blob.data() + pop.w_off);
-    std::vector<long> wp;
+    std::vector<v4i> wp;
     // the kernel instantiation covers nbp = {1,2,3,5} blocks and reads the weights of all of them: allocate (zero
     // rows) up to nbp, otherwise a 4-block layer (e.g. Cout = 208 in Lite2) reads past the packed array
     const int nbp_alloc = ps.NB <= 3 ? ps.NB : 5;
-    pack_weights(w, tout.c, Ce, Cp / 32, nbp_alloc, nullptr, wp);
-    long* dwp;
+    pack_weights64(w, tout.c, Ce, Cp / 64, nbp_alloc, wp);
+    v4i* dwp;
     int rc;
     if ((rc = upload(m, wp, &dwp))) return rc;
-    a.wp = dwp; a.bp = ps.bias; a.mp = ps.mult; a.KSp = Cp / 32;
+    a.wp = dwp; a.bp = ps.bias; a.mp = ps.mult; a.KSp = Cp / 64;
     a.zo = tout.zero_point; a.lop = pop.act_min; a.hip = pop.act_max;
     a.rqp = make_rq(a.zo, a.lop, a.hip);
   }
@@ -477,7 +478,8 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     const int8_t* wd = (const int8_t*)(m->blob.data() + dop.w_off);
     const int8_t* wpj = (const int8_t*)(m->blob.data() + pop.w_off);
     const int K = tin.c, KSe = a.KSe, nch3 = Ce / 48, KT = (kk + 1) / 2;
-    std::vector<long> we3((size_t)nch3 * KSe * 3 * 64, 0), wdm3((size_t)nch3 * 3 * KT * 64, 0), wp3;
+    std::vector<long> we3((size_t)nch3 * KSe * 3 * 64, 0), wdm3((size_t)nch3 * 3 * KT * 64, 0);
+    std::vector<v4i> wp3;
     int8_t* o = (int8_t*)we3.data();
     for (int c = 0; c < nch3; c++)
       for (int ks = 0; ks < KSe; ks++)
@@ -501,11 +503,12 @@ static int make_fused(vbt_model* m, int e_op, int d_op, int p_op, int a_op, Step
     std::vector<int> kmap((size_t)nch3 * 64, -1);
     for (int c = 0; c < nch3; c++)
       for (int q = 0; q < 48; q++) kmap[(size_t)c * 64 + q] = 48 * c + q;
-    pack_weights(wpj, tout.c, Ce, 2 * nch3, ps.NB <= 3 ? ps.NB : 5, &kmap, wp3);
-    long *d1, *d2, *d3;
+    pack_weights64(wpj, tout.c, Ce, nch3, ps.NB <= 3 ? ps.NB : 5, wp3, &kmap);
+    long *d1, *d2;
+    v4i* d3;
     int rc;
     if ((rc = upload(m, we3, &d1)) || (rc = upload(m, wdm3, &d2)) || (rc = upload(m, wp3, &d3))) return rc;
-    a.we3 = d1; a.wdm3 = d2; a.wp3 = d3; a.nch3 = nch3; a.KSp3 = 2 * nch3;
+    a.we3 = d1; a.wdm3 = d2; a.wp3 = d3; a.nch3 = nch3; a.KSp3 = nch3;
   }
   if (expand && tin.h * tin.w <= 400 && tout.h * tout.w <= 400) {
     // whole-image kernel (image_block.h): one contiguous record per 64-channel chunk

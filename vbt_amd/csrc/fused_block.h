@@ -35,7 +35,7 @@ struct FusedArgs {
   // (6 x {16, 24, 40, 80, 112}): no padded channels in the expand / depthwise stages.  nch3 == 0: not available.
   const long* we3;   // [(c*KSe + ks)*3 + t][lane]: cout = 48c + 12(i>>2) + 4t + (i&3)
   const long* wdm3;  // [(c*3 + cg)*KT + m][lane]: channel 48c + 16cg + i
-  const long* wp3;   // project weights, K-steps 2c, 2c+1 = channels 48c..48c+47 (+16 zero columns)
+  const v4i* wp3;    // project weights, K-step c (16x16x64 layout) = channels 48c..48c+47 (+16 zero columns)
   int nch3, KSp3;
   // depthwise
   const float* wd;  // [k*k][Ce_pad]
@@ -57,7 +57,7 @@ struct FusedArgs {
   // lane; the kernels rebuild the 16-byte operand in registers (diag_operand)
   const long* wd64c;
   // project
-  const long* wp;   // packed, K = Ce_pad
+  const v4i* wp;    // packed for the 16x16x64 MFMA (pack_weights64), K = Ce_pad, one K-step per 64-channel chunk
   const int* bp;
   const float* mp;
   int KSp, zo, lop, hip;
@@ -96,7 +96,7 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
 }
 
 constexpr int FB_EST = 80;  // E tile bytes per pixel (64 + 16: bank spread, 16-B aligned)
-constexpr int FB_DST = 72;  // D tile bytes per pixel
+constexpr int FB_DST = 80;  // D tile bytes per pixel: 16-byte aligned rows (the projection reads 16 bytes per lane), 20-dword pitch: conflict-free
 
 // KSE > 0: the expand has exactly KSE K-steps and its weights stay in registers for the whole chunk (the pixel-group
 // loop then issues no global loads); KSE == 0: K-steps are a runtime loop that streams the weights.
@@ -137,7 +137,7 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
   // start from LDS instead of from two more exposed L2 round trips (these kernels are latency chains, not bandwidth)
   bool stage_p = false;
   if constexpr (!EXPAND && NBP <= 2) stage_p = a.nchunks == 1;
-  unsigned char* WPS = D + 64 * PPW * FB_DST;    // [NBP][2][4][64] x 8 B
+  unsigned char* WPS = D + 64 * PPW * FB_DST;    // [NBP][4][64] x 16 B
   unsigned char* BPS = WPS + NBP * 4096;         // bias int[NBP*64] | mult float[NBP*64]
 
   // ---- stage L: input halo tile -> LDS ----
@@ -507,30 +507,21 @@ __device__ __forceinline__ void fused_block_body(const FusedArgs& a, int tile, u
       }
     }
     __syncthreads();
-    // ---- stage P: project accumulation, wave w <- pixel slots 16*PPW*w .. +16*PPW-1, K = this chunk's 64 channels ----
+    // ---- stage P: project accumulation, wave w <- pixel slots 16*PPW*w .. +16*PPW-1, K = this chunk's 64 channels: ONE 16x16x64 MFMA per
+    // (slot group, 16-channel tile) and one 16-byte operand read per slot group (two 16x16x32 and two 8-byte reads before) ----
+    {
+      v4i bv[PPW];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; k2++) {
-      long bv[PPW];
-#pragma unroll
-      for (int pp = 0; pp < PPW; pp++) bv[pp] = *(const long*)(D + ((wave * PPW + pp) * 16 + r) * FB_DST + 32 * k2 + 8 * g);
+      for (int pp = 0; pp < PPW; pp++) bv[pp] = *(const v4i*)(D + ((wave * PPW + pp) * 16 + r) * FB_DST + 16 * g);
 #pragma unroll
       for (int nb = 0; nb < NBP; nb++) {
-        if (stage_p) {
-          const long* w = (const long*)WPS + ((nb * 2 + k2) * 4) * 64 + lane;
+        const v4i* w = stage_p ? (const v4i*)WPS + (nb * 4) * 64 + lane
+                               : (NT == 3 ? a.wp3 + ((long)(nb * a.KSp3 + c) * 4) * 64 : a.wp + ((long)(nb * a.KSp + c) * 4) * 64) + lane;
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const long wv = w[t * 64];
+        for (int t = 0; t < 4; t++) {
+          const v4i wv = w[t * 64];
 #pragma unroll
-            for (int pp = 0; pp < PPW; pp++) acc[pp][nb][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wv, bv[pp], acc[pp][nb][t], 0, 0, 0);
-          }
-        } else {
-          const long* w = (NT == 3 ? a.wp3 + ((long)(nb * a.KSp3 + 2 * c + k2) * 4) * 64 : a.wp + ((long)(nb * a.KSp + 2 * c + k2) * 4) * 64) + lane;
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const long wv = w[t * 64];
-#pragma unroll
-            for (int pp = 0; pp < PPW; pp++) acc[pp][nb][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(wv, bv[pp], acc[pp][nb][t], 0, 0, 0);
-          }
+          for (int pp = 0; pp < PPW; pp++) acc[pp][nb][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, bv[pp], acc[pp][nb][t], 0, 0, 0);
         }
       }
     }
