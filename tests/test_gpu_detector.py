@@ -146,6 +146,44 @@ def test_explicit_clamps_bit_exact(tmp_path, model_path, oracle_lib, frames):
                     assert np.array_equal(it.read_tensor(tid, 2)[b], det.tensor(tid)), (flags, tid)
 
 
+def test_both_accumulator_flavours_bit_exact(tmp_path, model_path, oracle_lib, frames, monkeypatch):
+    """A conv whose int32 accumulators provably stay inside (-2^22, 2^22) starts them at bias + 0x4B400000 and reads them back as
+    floats (two packed adds instead of four v_cvt_f32_i32); the proof is 255 * sum|w| + |bias| < 2^22 per output
+    channel.  (a) VBT_NO_KBIAS=1: no conv takes that form; (b) a container with |bias| = 5e6 on some channels of every third conv:
+    the proof fails there (and the outputs saturate), the other convs keep the biased form.  Every materialised tensor and every
+    detection equals the oracle's in the fused plan modes either way."""
+    from vbt_amd.container import Container
+    from vbt_amd.interpreter import Interpreter
+    raw = bytearray(open(model_path, "rb").read())
+    c = Container(model_path)
+    bo = int(c.header["blob_offset"])
+    n = 0
+    for i, r in enumerate(c.ops):
+        if int(r["type"]) in (1, 2, 3) and i % 3 == 0:
+            cout = int(c.tensors[int(r["output"])]["c"])
+            b = np.frombuffer(raw, dtype="<i4", count=cout, offset=bo + int(r["b_off"]))
+            b[::5] = np.where(np.arange(len(b[::5])) % 2 == 0, 5_000_000, -5_000_000)
+            n += 1
+    assert n > 30
+    big = str(tmp_path / "bigbias.vbtm")
+    open(big, "wb").write(bytes(raw))
+    for path, env in ((model_path, "1"), (big, None), (big, "1")):
+        if env is None:
+            monkeypatch.delenv("VBT_NO_KBIAS", raising=False)
+        else:
+            monkeypatch.setenv("VBT_NO_KBIAS", env)
+        det = oracle_lib.OracleDetector(path)
+        for flags in (8, 0):
+            it = Interpreter(path, max_batch=2, flags=flags)
+            boxes, scores, classes, counts = it.detect(frames[:2])
+            for b in range(2):
+                ob, os_, oc, on = det.run(frames[b])
+                assert counts[b] == on and np.array_equal(scores[b], os_) and np.array_equal(boxes[b], ob), (path, env, flags)
+                for tid in range(1, it.num_tensors() - 1):
+                    if it.materialized(tid):
+                        assert np.array_equal(it.read_tensor(tid, 2)[b], det.tensor(tid)), (path, env, flags, tid)
+
+
 def test_extreme_frames_bit_exact(model_path, oracle_lib):
     """All-black, all-white, uniform noise and a 1-pixel checkerboard: inputs that drive many activations into the
     saturating ends of their int8 ranges (the requantisation leaves that clamp to the u8 conversion)."""
