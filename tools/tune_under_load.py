@@ -15,7 +15,9 @@ from vbt_amd.track import Pipeline
 from vbt_amd.container import Container
 
 plan_in, plan_out = sys.argv[1], sys.argv[2]
-n = 64
+n = int(os.environ.get("TUL_BATCH", "64"))      # clips per step; the trial plan is written for this batch
+KSTEPS = int(os.environ.get("TUL_STEPS", str(max(300, 19200 // n))))
+SUF = f".b{n}.f0"
 size = int(Container(bench.MODEL).header["image_size"])
 U = 16
 frames = torch.from_numpy(bench.make_frames(list(range(n)), 0, U, size)).cuda()
@@ -24,10 +26,10 @@ stream = torch.cuda.current_stream().cuda_stream
 TRIAL = "/tmp/plan_trial"
 
 
-def score(lines, reps=2, K=300):
-    with open(TRIAL + ".b64.f0", "w") as f:
+def score(lines, reps=2, K=KSTEPS):
+    with open(TRIAL + SUF, "w") as f:
         f.write("\n".join(lines) + "\n")
-    before = open(TRIAL + ".b64.f0").read()
+    before = open(TRIAL + SUF).read()
     os.environ["VBT_PLAN_FILE"] = TRIAL
     try:
         pipe = Pipeline(bench.MODEL, n, max_frames=K + 40, fps=60.0, detection_treshold=0.5, device=0, rows_per_frame=8)
@@ -35,7 +37,7 @@ def score(lines, reps=2, K=300):
         print(f"    rejected: {str(e)[:90]}", flush=True)
         torch.cuda.synchronize()
         return None
-    if open(TRIAL + ".b64.f0").read() != before:
+    if open(TRIAL + SUF).read() != before:
         del pipe
         return None                                  # the library did not accept the plan and re-tuned
     best = 0.0
@@ -105,6 +107,8 @@ for ln, opts in cands:
             s2 = score(trial)                                     # confirm
             if s2 is not None and s2 > base * 1.003:
                 lines, base, tag = trial, max(s, s2), "  <- accepted"
+                with open(plan_out, "w") as f:                    # (kept current: a search cut short by a time limit still leaves its best plan)
+                    f.write("\n".join(lines) + "\n")
         print(f"line {ln:2d}: '{o}' {s:.0f}{tag}", flush=True)
 with open(plan_out, "w") as f:
     f.write("\n".join(lines) + "\n")
