@@ -916,20 +916,38 @@ struct StepMeta {
 // round trip instead of 25 dependent ones by lane 0): threshold of reference odt.py:70-75 (score >= det_threshold), the
 // reorder of odt.py:102-118 and OC-SORT's own gate (score > det_thresh), order kept.  Returns the number of detections
 // handed to the tracker, or -1 when run_odt would have returned [] (the frame is skipped, track.py:180-181).  Uniform.
-__device__ inline int load_slot_detections(StepShared& sh, const float* boxes, const float* scores, const int* counts, int slot,
-                                           float det_threshold, double det_thresh, int lane) {
-  const int n = min(counts[slot], MAXD);
-  const float s = lane < n ? scores[slot * MAXD + lane] : 0.0f;
+// The slot's count, this lane's score and this lane's box are requested TOGETHER (the count used to gate the score load and the score
+// the box load: three dependent round trips at the head of every frame of a walk), and a walk requests frame f + 1's while it steps
+// through frame f.
+struct RawDet {
+  int n;
+  float s;
+  float4 b;   // ymin,xmin,ymax,xmax
+};
+__device__ __forceinline__ RawDet fetch_slot_detections(const float* boxes, const float* scores, const int* counts, int slot, int lane) {
+  const int l = min(lane, MAXD - 1);   // lanes past the 25 entries re-read the last one (never used)
+  RawDet d;
+  d.n = counts[slot];
+  d.s = scores[slot * MAXD + l];
+  d.b = *(const float4*)(boxes + ((size_t)slot * MAXD + l) * 4);
+  return d;
+}
+__device__ __forceinline__ int put_slot_detections(StepShared& sh, const RawDet& d, float det_threshold, double det_thresh, int lane) {
+  const int n = min(d.n, MAXD);
+  const float s = lane < n ? d.s : 0.0f;
   const bool kept = lane < n && s >= det_threshold;
   const bool used = kept && (double)s > det_thresh;
   const unsigned long long mk = __ballot(kept), mu = __ballot(used);
   if (used) {
     const int m = __popcll(mu & ((1ull << lane) - 1ull));
-    const float4 b = *(const float4*)(boxes + ((size_t)slot * MAXD + lane) * 4);  // ymin,xmin,ymax,xmax
-    sh.det[m][0] = (double)b.y; sh.det[m][1] = (double)b.x; sh.det[m][2] = (double)b.w; sh.det[m][3] = (double)b.z;
+    sh.det[m][0] = (double)d.b.y; sh.det[m][1] = (double)d.b.x; sh.det[m][2] = (double)d.b.w; sh.det[m][3] = (double)d.b.z;
     sh.det[m][4] = (double)s; sh.det[m][5] = 0.0;
   }
   return mk ? __popcll(mu) : -1;
+}
+__device__ inline int load_slot_detections(StepShared& sh, const float* boxes, const float* scores, const int* counts, int slot,
+                                           float det_threshold, double det_thresh, int lane) {
+  return put_slot_detections(sh, fetch_slot_detections(boxes, scores, counts, slot, lane), det_threshold, det_thresh, lane);
 }
 
 __global__ __launch_bounds__(64) void tracker_from_det_kernel(ClipState* states, Row* rows, int rows_cap, const float* boxes,
@@ -1000,10 +1018,14 @@ __global__ __launch_bounds__(64) void tracker_seq_kernel(ClipState* states, Row*
   // access was a FLAT instruction - slower to issue, and each one counted on both wait counters, so that every wait drained both
   // queues (the walk was 5 600 instructions with 270 flat accesses and 240 waits).
   auto walk = [&](ClipState& state) {
+    RawDet cur = fetch_slot_detections(boxes, scores, counts, r.slot0, lane);
     for (int f = 0; f < r.n_frames; f++) {
+      // frame f + 1's detections are requested now and looked at in the next iteration (the last frame re-requests itself)
+      const RawDet nxt = fetch_slot_detections(boxes, scores, counts, r.slot0 + min(f + 1, r.n_frames - 1) * r.slot_stride, lane);
       __syncthreads();  // the previous frame's readers of sh.det are done
-      const int nd = load_slot_detections(sh, boxes, scores, counts, r.slot0 + f * r.slot_stride, det_threshold, p.det_thresh, lane);
+      const int nd = put_slot_detections(sh, cur, det_threshold, p.det_thresh, lane);
       __syncthreads();
+      cur = nxt;
       if (nd < 0) continue;
       const double frame_time = (double)(r.frame0 + f * r.frame_step) / r.fps;
       ocsort_step(state, myrows, rows_cap, sh, nd, frame_time, p, q44, q66, lane);
