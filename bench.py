@@ -433,6 +433,7 @@ def extra_measurements(torch, pipe, frames, frames_np, n, K, W, U, fbytes, strea
         t0 = time.perf_counter()
         for i in range(steps):
             pipe.step(host[(W + i) % Uh], stream)
+        host_fed.enqueue_ms = (time.perf_counter() - t0) * 1e3      # host time spent enqueueing (a copy that blocks the host shows here)
         best, rows_n, nph, ovf, ph = pipe.close(cap=PH)
         counts, rows = pipe.rows_all(out=rows_host)
         torch.cuda.synchronize()
@@ -444,7 +445,7 @@ def extra_measurements(torch, pipe, frames, frames_np, n, K, W, U, fbytes, strea
     out["value_h2d_inclusive"] = Kx * n / dt
     out["h2d_inclusive"] = {"frames_per_s": Kx * n / dt, "ms_per_step": dt / Kx * 1e3, "steps": Kx, "warmup": W,
                             "roofline_frac_8d": roofline_frac_8d(Kx * n / dt, 0, n),
-                            "h2d_bytes_per_step": int(host[0].numel()), "rows_d2h_bytes": d2h,
+                            "h2d_bytes_per_step": int(host[0].numel()), "rows_d2h_bytes": d2h, "enqueue_ms": host_fed.enqueue_ms,
                             "note": "uint8 frames in pinned host memory -> hipMemcpyAsync on the copy stream (two steps ahead of the "
                                     "forwards) -> detect+NMS+track -> clip close -> all DataFrame rows copied to pinned host memory; the first "
                                     "forward cannot start before its own 19.7 MB copy (0.36 ms at 54 GB/s) has landed, which a short run pays in full"}
