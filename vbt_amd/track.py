@@ -440,9 +440,7 @@ class Pipeline:
             self._stage_idx += 1
             self._staging(j, host_frames.shape)
             C = self._copy_stream
-            C.wait_event(self._ev_in[k])
-            if self._stage_free[j] is not None:
-                C.wait_event(self._stage_free[j])                    # the forward that last read this staging buffer is done
+            self._host_copy_gate(j)
             with torch.cuda.stream(C):
                 self._stage[j].copy_(host_frames, non_blocking=True)
             ev = torch.cuda.Event()
@@ -490,6 +488,17 @@ class Pipeline:
         # own stream: keep depth-1 detector steps ahead of the tracker; inline: the step follows its forward directly
         while len(self._pending) >= (1 if self._trk_inline else self.depth):
             self._enqueue_tracker(self._pending.pop(0))
+
+    def _host_copy_gate(self, j):
+        """Before an H2D copy into staging buffer j is enqueued: the forward that last read the buffer must be done.  The wait is on
+        the HOST (the event is `depth + 2` steps old: it has completed unless the caller is that many steps ahead of the GPU, and then
+        blocking the caller is the back-pressure wanted), NOT a stream wait on the copy stream: a cross-stream event wait in front of
+        a DMA copy makes hipMemcpyAsync itself block the calling thread on this stack - 0.6-0.9 ms per step instead of 0.2 - and costs
+        the host-fed pipeline 6 % (97.5 k -> 103.9 k frames/s without it, profiles/r04_h2d_pinned_order.md).  Frames in host memory are
+        ready when the call is made, so the copy stream does not wait for the caller's stream either."""
+        ev = self._stage_free[j]
+        if ev is not None:
+            ev.synchronize()
 
     def _staging(self, j, shape):
         """Staging buffer j of the host-fed / gathered input ring with (at least) the given shape.  A buffer that has to be
@@ -568,9 +577,7 @@ class Pipeline:
             on_host = dev0.type == "cpu"
             if on_host:
                 C = self._copy_stream
-                C.wait_event(self._ev_in[k])
-                if self._stage_free[j] is not None:
-                    C.wait_event(self._stage_free[j])
+                self._host_copy_gate(j)
                 with torch.cuda.stream(C):
                     for src, r in zip(frames, ra):
                         st[r.slot0:r.slot0 + r.n_frames].copy_(src[:r.n_frames], non_blocking=True)
@@ -602,9 +609,7 @@ class Pipeline:
                 self._stage_idx += 1
                 st = self._staging(j, (self.n,) + tuple(frames.shape[1:]))
                 C = self._copy_stream
-                C.wait_event(self._ev_in[k])
-                if self._stage_free[j] is not None:
-                    C.wait_event(self._stage_free[j])
+                self._host_copy_gate(j)
                 with torch.cuda.stream(C):
                     st[:frames.shape[0]].copy_(frames, non_blocking=True)
                 ev = torch.cuda.Event()
