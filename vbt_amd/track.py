@@ -681,6 +681,7 @@ class Pipeline:
         """Measurement split: `count` tracker steps of all clips on the detections sitting in ring slot `slot`."""
         if self.n_trk != self.n:
             raise RuntimeError("tracker_only_steps needs one tracker clip per detector slot")
+        self._flush_group()                                          # (deferred steps first: tracker launches stay in frame order)
         b, s, c, cnt = self._bufs[slot]
         T = self._trk_stream
         T.wait_event(self._ev_det[slot])
