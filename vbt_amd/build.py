@@ -52,7 +52,8 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    # a prerequisite that no longer exists (a header deleted or renamed, still listed in the depfile) makes the target stale too
+    return any(not os.path.exists(d) or os.path.getmtime(d) > t for d in deps)
 
 
 def needs_build():

@@ -25,6 +25,17 @@ struct RoctxRange {
   bool on;
 };
 
+// More than 64 KB of dynamic LDS is an opt-in per kernel AND per device (hipFuncSetAttribute acts on the current device's code object).
+// Every launch site keeps its own per-device record; a refusal is an error (VBT_ERR_HIP with the text set), not a silent launch failure
+// that surfaces at a later synchronisation or inside a stream capture.
+struct LdsOptIn { signed char dev[64] = {0}; };
+bool lds_opt_in(const void* fn, LdsOptIn* state);
+#define VBT_LDS_OPT_IN(...)                                                                          \
+  do {                                                                                               \
+    static vbt::LdsOptIn lds_state_;                                                                 \
+    if (!vbt::lds_opt_in(reinterpret_cast<const void*>(&__VA_ARGS__), &lds_state_)) return VBT_ERR_HIP; \
+  } while (0)
+
 #define VBT_HIP_CHECK(expr)                                                              \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \

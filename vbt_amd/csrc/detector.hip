@@ -40,6 +40,20 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+bool lds_opt_in(const void* fn, LdsOptIn* state) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("lds_opt_in: no current HIP device"); return false; }
+  if (state->dev[dev] > 0) return true;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("device %d refuses more than 64 KB of dynamic LDS for a kernel that needs it: %s", dev, hipGetErrorString(e));
+    return false;
+  }
+  state->dev[dev] = 1;
+  return true;
+}
+
 #include "op_kernels.h"   // the single-op kernels (pw_a / pw_b / pw_c / pw_d, stem, depthwise, add, pool, resize, decode + NMS, frame resize)
 
 // ------------------------------------------------------------------------------------------
@@ -147,6 +161,7 @@ struct vbt_model {
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipStream_t cap_stream = nullptr;
   int graph_max_batch = 0;  // 0 = graphs off
+  bool ran_eager = false;   // one forward has been enqueued outside a stream capture (per-device LDS opt-ins, lazy uploads)
   std::vector<void*> owned;  // device allocations to free
   // Parameter pool: weights, biases, multipliers and argument tables are sub-allocated from a few large device chunks and
   // mirrored on the host; flush_uploads() brings a chunk up to date with ONE copy (a model used to issue ~1 800 small blocking
@@ -1469,6 +1484,8 @@ static bool pwm_mergeable(const vbt_model* m, const Step& s) {
 static void merge_side_convs(vbt_model* m) {
   static const bool off = getenv("VBT_NO_PW_MERGE") != nullptr;
   if (off || (m->flags & (VBT_MODEL_NO_FUSION | VBT_MODEL_NO_PW_MERGE))) return;
+  // sub-batch streams: the merged launch's problem list holds whole-batch pointers (the guard band_ok() has; n_sub is final by now)
+  if (m->n_sub > 1) return;
   const int ns = (int)m->steps.size(), no = (int)m->ops.size();
   // which step runs which graph op: the ops a step names, then (absorbed resamples / partial sums) the step of their consumer
   std::vector<int> step_of(no, -1);
@@ -2153,11 +2170,7 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         if (m->post_tables_host[q + 128] >= m->hdr.nms_score_threshold) qmin = q; else break;
       p.qmin = qmin;
       const int lds = post_lds_bytes(p.A);
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&postprocess_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-      }
+      if (lds > 64 * 1024) VBT_LDS_OPT_IN(postprocess_kernel);
       if (lds > 160 * 1024 || p.A > 65535) { set_error("decode + NMS: %d anchors do not fit the kernel (LDS %d bytes, 16-bit anchor index)", p.A, lds); return VBT_ERR_CAPACITY; }
       postprocess_kernel<<<dim3((unsigned)B), POST_THREADS, lds, st>>>(p, boxes, scores, classes, counts);
       break;
@@ -2406,6 +2419,13 @@ static int forward(vbt_model* m, const uint8_t* frames_dev, int B, hipStream_t s
     }
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
+    if (!m->ran_eager) {
+      // The first forward of a model never runs inside a capture: the per-device LDS opt-ins of its kernels (hipFuncSetAttribute) and any
+      // failure they report happen here, eagerly, on the caller's stream (same buffers, same results as the replay that follows).
+      const int rc0 = enqueue_forward(m, frames_dev, B, st, boxes, scores, classes, counts, nullptr);
+      if (rc0) return rc0;
+      m->ran_eager = true;
+    }
     VBT_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = enqueue_forward(m, frames_dev, B, m->cap_stream, boxes, scores, classes, counts, nullptr);
     hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
@@ -2656,9 +2676,15 @@ int vbt_detect(vbt_model* m, const uint8_t* frames, int B, int frames_on_device,
     // filled on the host (four copies into pageable memory used to be four staged transfers)
     const int md = m->hdr.max_detections;
     const size_t mb = (size_t)m->max_batch;
-    VBT_HIP_CHECK(hipMemcpyAsync(m->out_host, m->out_boxes, m->out_bytes, hipMemcpyDeviceToHost, st));
+    const unsigned char* d = (const unsigned char*)m->out_boxes;
+    unsigned char* h = m->out_host;
+    if (B == m->max_batch) {
+      VBT_HIP_CHECK(hipMemcpyAsync(h, d, m->out_bytes, hipMemcpyDeviceToHost, st));
+    } else {   // only the B-frame prefix of each of the four tensors (an interpreter created for 256 frames and called with 1 moved 615 KB)
+      const size_t off[4] = {0, mb * md * 16, mb * md * 20, mb * md * 24}, len[4] = {(size_t)B * md * 16, (size_t)B * md * 4, (size_t)B * md * 4, (size_t)B * 4};
+      for (int i = 0; i < 4; i++) VBT_HIP_CHECK(hipMemcpyAsync(h + off[i], d + off[i], len[i], hipMemcpyDeviceToHost, st));
+    }
     VBT_HIP_CHECK(hipStreamSynchronize(st));
-    const unsigned char* h = m->out_host;
     memcpy(boxes, h, (size_t)B * md * 16);
     memcpy(scores, h + mb * md * 16, (size_t)B * md * 4);
     memcpy(classes, h + mb * md * 20, (size_t)B * md * 4);

@@ -5,26 +5,23 @@
 
 namespace vbt {
 
-static void band_attrs() {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_one_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv_band_one_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+static int band_attrs() {
+  VBT_LDS_OPT_IN(sepconv_band_kernel);
+  VBT_LDS_OPT_IN(sepconv_band_one_kernel);
+  VBT_LDS_OPT_IN(sepconv_band_wide_kernel);
+  VBT_LDS_OPT_IN(sepconv_band_one_wide_kernel);
+  return VBT_OK;
 }
 
 int launch_band_one(const BandArgs& a, unsigned grid, int lds_bytes, hipStream_t st) {
-  band_attrs();
+  if (band_attrs()) return VBT_ERR_HIP;
   if (a.C == 64) sepconv_band_one_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
   else sepconv_band_one_wide_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
   return VBT_OK;
 }
 
 int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, int C, unsigned grid, int lds_bytes, hipStream_t st) {
-  band_attrs();
+  if (band_attrs()) return VBT_ERR_HIP;
   if (C == 64) sepconv_band_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES, lds_bytes, st>>>(d_probs, mt);
   else sepconv_band_wide_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES_WIDE, lds_bytes, st>>>(d_probs, mt);
   return VBT_OK;
@@ -34,13 +31,9 @@ int launch_expdw(const ExpDwArgs& a, int k, int stride, int KS64, unsigned grid_
   const dim3 grid(grid_x);
 #define XD_LAUNCH(KK, S)                                                                                             \
   do {                                                                                                               \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw_image_kernel<KK, S, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
+    VBT_LDS_OPT_IN(expdw_image_kernel<KK, S, 2>);                                                                    \
+    VBT_LDS_OPT_IN(expdw_image_kernel<KK, S, 3>);                                                                    \
+    VBT_LDS_OPT_IN(expdw_image_kernel<KK, S, 4>);                                                                    \
     if (KS64 == 2) expdw_image_kernel<KK, S, 2><<<grid, XD_THREADS, lds_bytes, st>>>(a);                             \
     else if (KS64 == 3) expdw_image_kernel<KK, S, 3><<<grid, XD_THREADS, lds_bytes, st>>>(a);                        \
     else expdw_image_kernel<KK, S, 4><<<grid, XD_THREADS, lds_bytes, st>>>(a);                                       \
@@ -53,30 +46,27 @@ int launch_expdw(const ExpDwArgs& a, int k, int stride, int KS64, unsigned grid_
 }
 
 template <int KK, int S, int KS64, int NW, int GPW>
-static void launch_expdw2_t(const ExpDw2Args& a, unsigned grid, int lds_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&expdw2_kernel<KK, S, KS64, NW, GPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+static int launch_expdw2_t(const ExpDw2Args& a, unsigned grid, int lds_bytes, hipStream_t st) {
+  VBT_LDS_OPT_IN(expdw2_kernel<KK, S, KS64, NW, GPW>);
   expdw2_kernel<KK, S, KS64, NW, GPW><<<dim3(grid), 64 * NW, lds_bytes, st>>>(a);
+  return VBT_OK;
 }
 
 int launch_expdw2(const ExpDw2Args& a, int k, int stride, int KS64, int nw, int gpw, unsigned grid, int lds_bytes, hipStream_t st) {
 #define XD2_GPW(KK, KS)                                                                    \
   do {                                                                                     \
     if (stride == 2) {   /* 16 waves only */                                               \
-      if (gpw == 1) launch_expdw2_t<KK, 2, KS, 16, 1>(a, grid, lds_bytes, st);             \
-      else if (gpw == 2) launch_expdw2_t<KK, 2, KS, 16, 2>(a, grid, lds_bytes, st);        \
-      else launch_expdw2_t<KK, 2, KS, 16, 4>(a, grid, lds_bytes, st);                      \
+      if (gpw == 1) { if (launch_expdw2_t<KK, 2, KS, 16, 1>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }             \
+      else if (gpw == 2) { if (launch_expdw2_t<KK, 2, KS, 16, 2>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }        \
+      else { if (launch_expdw2_t<KK, 2, KS, 16, 4>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }                      \
     } else if (nw == 16) {                                                                 \
-      if (gpw == 1) launch_expdw2_t<KK, 1, KS, 16, 1>(a, grid, lds_bytes, st);             \
-      else if (gpw == 2) launch_expdw2_t<KK, 1, KS, 16, 2>(a, grid, lds_bytes, st);        \
-      else launch_expdw2_t<KK, 1, KS, 16, 4>(a, grid, lds_bytes, st);                      \
+      if (gpw == 1) { if (launch_expdw2_t<KK, 1, KS, 16, 1>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }             \
+      else if (gpw == 2) { if (launch_expdw2_t<KK, 1, KS, 16, 2>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }        \
+      else { if (launch_expdw2_t<KK, 1, KS, 16, 4>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }                      \
     } else {                                                                               \
-      if (gpw == 2) launch_expdw2_t<KK, 1, KS, 8, 2>(a, grid, lds_bytes, st);              \
-      else if (gpw == 4) launch_expdw2_t<KK, 1, KS, 8, 4>(a, grid, lds_bytes, st);         \
-      else launch_expdw2_t<KK, 1, KS, 8, 7>(a, grid, lds_bytes, st);                       \
+      if (gpw == 2) { if (launch_expdw2_t<KK, 1, KS, 8, 2>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }              \
+      else if (gpw == 4) { if (launch_expdw2_t<KK, 1, KS, 8, 4>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }         \
+      else { if (launch_expdw2_t<KK, 1, KS, 8, 7>(a, grid, lds_bytes, st)) return VBT_ERR_HIP; }                       \
     }                                                                                      \
   } while (0)
 #define XD2_KS(KK)                  \
