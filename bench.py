@@ -378,6 +378,7 @@ def main():
                        "clips_per_gpu": n, "batch": n, "frames_per_clip": K, "model_file": os.path.basename(MODEL),
                        "weights": "seeded synthetic (PCG64), post-training int8 quantised", "parallelism": f"clip-sharded x{world}",
                        "pipeline_depth": int(os.environ.get("VBT_PIPELINE_DEPTH", "3"))},
+            "metric_definition": "resident",
             "value_is": "the contract run and nothing before it: W warm-up steps, K timed steps + clip close, frames resident in HBM; value_settled = "
                         "the same run repeated after a clock-settle phase; value_h2d_inclusive = SURVEY 8d's host-to-host metric, same W and K",
             "roofline_frac_8d": roofline_frac_8d(total_frames / dt / world, 0, n),
@@ -496,6 +497,24 @@ def _timed(torch, body, reps=2):
     return best
 
 
+def host_cost_per_step(pipe, fr, fb, U, stream, steps=8):
+    """Host microseconds one Pipeline.step() costs when nothing makes it wait: `steps` calls (fewer than the ring holds) into an idle
+    pipeline, timed on the host, best of 20 rounds - the Python / ctypes / HIP-runtime enqueue cost per step, apart from the GPU's pace."""
+    import torch
+    best = None
+    n = max(1, min(steps, pipe.depth))
+    for _ in range(20):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(n):
+            pipe.step(fr.data_ptr() + (t % U) * fb, stream)
+        dt = (time.perf_counter() - t0) / n
+        best = dt if best is None else min(best, dt)
+    torch.cuda.synchronize()
+    pipe.reset()
+    return best * 1e6
+
+
 def other_configs(torch, dev):
     """BASELINE.json configs 2, 4 and 5 and the small-batch points, each as whole-clip runs (clip close + rows on the host
     inside the timed region), frames resident in HBM."""
@@ -518,15 +537,24 @@ def other_configs(torch, dev):
         fb = fr[0].numel()
         pipe = Pipeline(MODEL, nb, max_frames=T, fps=60.0)
 
+        enq = []
+
         def body():
             pipe.reset()
+            t0 = time.perf_counter()
             for t in range(T):
                 pipe.step(fr.data_ptr() + (t % U) * fb, stream)
+            enq.append(time.perf_counter() - t0)
             pipe.close(cap=64)
             pipe.rows_all()
         dt = _timed(torch, body)
         fps = nb * T / dt
+        # enqueue_ms: host time inside the T step() calls of a run (they return as soon as the work is queued; the host blocks only on the
+        # back-pressure of a full ring).  enqueue_us_per_step against ms_per_step says whether the host or the GPU paces the run; the host's own
+        # cost per step is measured with the GPU out of the way: detector-only steps into an idle, 1-deep queue cannot be isolated, so it is
+        # the minimum over the runs of (enqueue time / steps), which is the GPU's pace when the host is NOT the limiter.
         return {"frames_per_s": fps, "ms_per_step": dt / T * 1e3, "batch": nb, "frames_per_clip": T, "roofline_frac_8d": roofline_frac_8d(fps, 0, nb),
+                "enqueue_ms": min(enq) * 1e3, "enqueue_us_per_step": min(enq) / T * 1e6, "host_us_per_step_unblocked": host_cost_per_step(pipe, fr, fb, U, stream),
                 "note": f"{nb} clip(s), one frame per clip per step (the forward is a replayed hipGraph), {pipe.depth} forwards in flight"}
     guarded("b1", lambda: small_batch(1, 2048))
     guarded("b8", lambda: small_batch(8, 1024))
@@ -546,7 +574,32 @@ def other_configs(torch, dev):
         def body():
             res["rows"] = len(track(frames, it, detection_treshold=0.5, fps=60.0)["id"])
         dt = _timed(torch, body)
-        return {"frames_per_s": T / dt, "ms_per_frame": dt / T * 1e3, "frames": T, "rows": res["rows"],
+        # where a frame's time goes (one more, instrumented pass): the blocking C call of the detector (H2D + batch-1 forward + packed D2H),
+        # the Python around it inside run_odt (preprocess_image, the list of dicts), OCSort.update (C call + packed read-back), the loop's own Python
+        import vbt_amd.track as vt
+        from vbt_amd.ocsort import OCSort
+        acc = {"c_detect": 0.0, "run_odt": 0.0, "update": 0.0}
+        o_odt, o_upd, o_det = vt.run_odt, OCSort.update, Interpreter.detect
+
+        def timed(key, fn):
+            def w(*a, **k):
+                t0 = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    acc[key] += time.perf_counter() - t0
+            return w
+        vt.run_odt, OCSort.update, Interpreter.detect = timed("run_odt", o_odt), timed("update", o_upd), timed("c_detect", o_det)
+        try:
+            t0 = time.perf_counter()
+            body()
+            tot = time.perf_counter() - t0
+        finally:
+            vt.run_odt, OCSort.update, Interpreter.detect = o_odt, o_upd, o_det
+        split = {"detector_c_call_us": acc["c_detect"] / T * 1e6, "run_odt_python_us": (acc["run_odt"] - acc["c_detect"]) / T * 1e6,
+                 "ocsort_update_us": acc["update"] / T * 1e6, "loop_python_us": (tot - acc["run_odt"] - acc["update"]) / T * 1e6}
+        return {"frames_per_s": T / dt, "ms_per_frame": dt / T * 1e3, "frames": T, "rows": res["rows"], "host_split_us_per_frame": split,
+                "enqueue_ms": None, "enqueue_note": "every call of this loop blocks until its result is on the host: there is no enqueue phase; host_split_us_per_frame is the breakdown",
                 "note": "vbt_amd.track.track(): the per-frame loop of reference track.py:159-234 with Interpreter / run_odt / OCSort swapped in "
                         "(INTEGRATION.md option A); every frame starts in host memory and every call returns host results, as in the reference"}
     guarded("dropin_per_frame", dropin)
@@ -575,6 +628,47 @@ def other_configs(torch, dev):
                 "note": "one 4096-frame clip, 64 consecutive frames per detector batch, OC-SORT walks the run in frame order inside one launch "
                         "(vbt_tracker_update_from_detections_seq): bound by the sequential tracker walk, not by the detector"}
     guarded("clip1_time_batched", clip1)
+
+    # ---- the tracker on the REFERENCE's load: clip 001's own boxes (dfs_ocsort: <= 3 plates per frame, 2 ids) fed as detector outputs to the
+    #      time-batched walk, 64 frames per launch like clip1_time_batched; the synthetic detector keeps ~10 tracks alive, the reference 2-3 ----
+    def clip1_reference():
+        from vbt_amd import _lib
+        from vbt_amd.ocsort import MultiClipTracker
+        L = _lib.lib()
+        a = np.load(os.path.join(ROOT, "tests", "golden", "dfs_ocsort_all.npz"))
+        fps = float(json.load(open(CORPUS_META))["001"][1])
+        g = {k: a[f"c001_{k}"] for k in ("time", "x", "y", "norm_plate_height", "norm_plate_width")}
+        fno = np.rint(g["time"] * fps).astype(np.int64)                  # 1-based frame numbers (time = frame_count / fps, track.py:161,169)
+        T = int(fno.max())
+        boxes = np.zeros((T, 25, 4), np.float32)
+        scores = np.zeros((T, 25), np.float32)
+        counts = np.zeros(T, np.int32)
+        for f, x, y, h, w in zip(fno, g["x"], g["y"], g["norm_plate_height"], g["norm_plate_width"]):
+            i = counts[f - 1]
+            boxes[f - 1, i] = (y - h / 2, x - w / 2, y + h / 2, x + w / 2)   # detector layout ymin,xmin,ymax,xmax (odt.py:64-66)
+            scores[f - 1, i] = 0.9
+            counts[f - 1] = i + 1
+        db, ds, dc = (torch.from_numpy(v).to(dev) for v in (boxes, scores, counts))
+        trk = MultiClipTracker(1, 8 * T + 75, max_age=30, asso_func="diou", iou_threshold=0.1)
+        F = 64
+        res = {}
+
+        def body():
+            trk.reset()
+            for f0 in range(0, T, F):
+                nf = min(F, T - f0)
+                run = (_lib.Run * 1)(_lib.Run(0, f0, 1, nf, f0 + 1, 1, fps))
+                _lib.check(L.vbt_tracker_update_from_detections_seq(trk.handle, db.data_ptr(), ds.data_ptr(), dc.data_ptr(), T, run, 1, 0.5, stream))
+            trk.finish(0.45, stream=stream)
+            best, rows_n, nph, ovf, ph = trk.summary(cap=64)
+            res.update(rows=int(rows_n.sum()), phases=int(nph.sum()), best_id=int(best[0]))
+        dt = _timed(torch, body, reps=3)
+        stepped = int((counts > 0).sum())
+        return {"us_per_stepped_frame": dt / stepped * 1e6, "clip_frames_per_s": T / dt, "frames": T, "stepped_frames": stepped, "rows": res["rows"], "phases": res["phases"],
+                "export_id": res["best_id"], "detections_per_stepped_frame": float(counts.sum()) / stepped,
+                "note": "OC-SORT walk alone on the reference's own load: clip 001's dfs_ocsort boxes (tests/golden/dfs_ocsort_all.npz) as detector outputs, "
+                        "64 frames per tracker launch + clip close; compare with clip1_time_batched, whose synthetic detector keeps ~10 tracks alive"}
+    guarded("clip1_reference_boxes", clip1_reference)
 
     # ---- 64 clips x 4 consecutive frames per detector batch (B = 256): what time-batching adds on top of the clip batch ----
     def b64x4():

@@ -184,6 +184,123 @@ int vbt_tracker_summary(vbt_tracker* t, int32_t* best_ids, int32_t* n_rows, int3
  * rows_host may be pinned host memory (one DMA) or pageable. */
 int vbt_tracker_rows_all(vbt_tracker* t, int32_t* counts, void* rows_host, int cap, void* stream);
 
+/* ------------------------------------------------------------------ pipeline ----------------
+ * Replaces the clip loop of the reference (track.py:129-260: `while cap.isOpened()` -> cap.read -> run_odt -> OCSort.update ->
+ * row assembly, then the export of track.py:103-126 and analyze_df of plot.py:33-47) as ONE object behind the C ABI: SURVEY.md 8b's
+ * "fused on-device path".  The handle owns everything the fast path needs and nothing of it lives in the caller's language:
+ *   - `depth` detector instances (activation arenas) on `depth` HIP streams of their own, each checked at creation to sit on its own
+ *     hardware queue (a pipeline whose busy streams share a queue loses a third of its throughput); the reference runs one
+ *     interpreter.invoke() at a time (odt.py:58-61) - the detector has no state, so consecutive steps may overlap;
+ *   - a ring of detector output slots and the events that order detector(t) -> tracker(t) -> slot reuse; the OC-SORT steps stay in
+ *     frame order (track.py:186 is sequential per clip);
+ *   - a copy stream with a ring of depth + 2 device staging buffers: frames handed over in host memory (the reference's situation,
+ *     track.py:160) are uploaded up to two steps ahead of their forward; with frames at source resolution only the rows the bilinear
+ *     resize of odt.py:10-19 reads are uploaded;
+ *   - for batches of <= 8 frames, groups of `depth` tracker steps walked by one launch (the forward of a small batch is launch latency).
+ * One handle is used by one host thread at a time.  Every call only ENQUEUES work unless its comment says it synchronises.
+ * Frames: uint8 [*,H,W,3]; H,W = the network resolution (vbt_model_input_shape) unless src_h/src_w say otherwise.
+ */
+typedef struct vbt_pipeline vbt_pipeline;
+typedef struct {
+  int32_t n_slots;           /* frames per detector batch (>= 1) */
+  int32_t n_clips;           /* clips the tracker follows; 0 = n_slots (one clip per slot) */
+  int32_t rows_cap;          /* capacity of each clip's row log (rows = emitted (id,time,...) records) */
+  int32_t device;
+  int32_t depth;             /* forwards in flight, 1..8; 0 = default (environment VBT_PIPELINE_DEPTH, else 4 for n_slots <= 8, else 3) */
+  int32_t tracker_stream;    /* where a frame's OC-SORT step runs: 0 = default (VBT_TRACKER_STREAM, else inline from depth 3), 1 = on a
+                                stream of its own, 2 = inline at the end of the forward's stream */
+  int32_t defer;             /* tracker steps of a small batch walked in groups of `depth`: -1 = default (VBT_TRACKER_DEFER, else on
+                                for n_slots <= 8 with one clip per slot), 0 = off, 1 = on */
+  int32_t selfcheck;         /* forwards on a blank batch per detector instance at creation: -1 = default (VBT_PIPELINE_SELFCHECK, else 1) */
+  int32_t strict_placement;  /* busy streams that cannot be put on distinct hardware queues: 1 = vbt_pipeline_create fails with
+                                VBT_ERR_STATE, 0 = a note on stderr, -1 = environment VBT_STRICT_PLACEMENT (default 0) */
+  int32_t model_flags;       /* vbt_model_create_ex flags; VBT_MODEL_DEFAULT_FLAGS */
+  float detection_threshold; /* detection_treshold of reference track.py:129,174 / odt.py:70-75 */
+  float reserved0;
+  double plate_diameter;     /* VelocityTracker(plate_diameter, diff_threshold, min_distance), reference VelocityTracker.py:16 */
+  double diff_threshold;
+  double min_distance;
+  vbt_tracker_params tracker; /* OCSort(...) of reference track.py:157 */
+} vbt_pipeline_params;
+/* the reference's settings: OCSort(max_age=30, asso_func="diou", iou_threshold=0.1) (track.py:22,157), threshold 0.5,
+ * VelocityTracker(0.45, 0.6, 0.1); everything else 0 / -1 = default */
+void vbt_pipeline_default_params(vbt_pipeline_params* p);
+/* fps_host [n_clips]: cap.get(cv2.CAP_PROP_FPS) of every clip (reference track.py:138) */
+int vbt_pipeline_create(const char* container_path, const vbt_pipeline_params* p, const double* fps_host, vbt_pipeline** out);
+void vbt_pipeline_destroy(vbt_pipeline* p);
+
+/* One frame of every clip: frames = uint8 [n_slots,H,W,3], frame number frame_count + 1 of each clip (track.py:161), time stamp
+ * frame_count / fps (track.py:169).  frames_on_device != 0: a device pointer, valid on `caller_stream` when the call is made (the
+ * forward waits for that point of the stream) and left untouched until the step has run (up to `depth` steps later).
+ * frames_on_device == 0: host memory, final when the call is made; pinned memory is copied by DMA on the copy stream up to two steps
+ * ahead and must stay untouched until the step has run; the call blocks only when the caller is depth + 2 steps ahead of the GPU.
+ * src_h / src_w > 0: the frames are at source resolution and go through preprocess_image (odt.py:10-19) on the device; swap_rb: BGR
+ * input (track.py:171).  active [n_slots] (or NULL): clips that have a frame in this step; the others keep their state and frame
+ * counter.  clip_map / frame_idx [n_slots] (or NULL): slot i carries frame number frame_idx[i] (1-based) of clip clip_map[i] (-1:
+ * empty slot) - more clips than slots.  track == 0: detector only (measurement splits). */
+int vbt_pipeline_step(vbt_pipeline* p, const uint8_t* frames, int frames_on_device, int src_h, int src_w, int swap_rb,
+                      const uint8_t* active, const int32_t* clip_map, const int32_t* frame_idx, int track, void* caller_stream);
+/* Time-batched step: the batch holds RUNS of consecutive frames of a clip (vbt_run; fps <= 0 = the clip's own, slot_stride 0 = 1);
+ * OC-SORT walks every run in frame order inside one launch.  Either `frames` is the assembled batch [B,H,W,3] (B = slots the runs
+ * cover) or it is NULL and run_sources[i] points at the n_frames contiguous frames of run i (all device or all host): the batch is
+ * then assembled here (one gather launch, or one copy per run on the copy stream).  The runs must cover slots 0..B-1 without a hole.
+ * out_* != NULL (with track == 0): the detections go to these device buffers ([B,25,4], [B,25], [B,25], [B]) instead of the ring -
+ * the frame-major multi-GPU mode collects them for its gather. */
+int vbt_pipeline_step_runs(vbt_pipeline* p, const uint8_t* frames, const uint8_t* const* run_sources, int frames_on_device,
+                           const vbt_run* runs, int n_runs, int src_h, int src_w, int swap_rb, int track,
+                           float* out_boxes, float* out_scores, float* out_classes, int32_t* out_counts, void* caller_stream);
+/* frames read from the source but not processed (`frame_count % 16`, track.py:161-167): they advance the clip time only */
+int vbt_pipeline_skip_frames(vbt_pipeline* p, int n);
+int vbt_pipeline_set_frame_count(vbt_pipeline* p, int frame_count);
+/* back to frame 0 of fresh clips; models, streams and buffers are kept (synchronises) */
+int vbt_pipeline_reset(vbt_pipeline* p);
+/* `stream` waits for every forward enqueued so far (after detector-only steps their outputs are then safe to read on it) */
+int vbt_pipeline_join_detectors(vbt_pipeline* p, void* stream);
+/* Clip close (track.py:103-126 export id, plot.py:33-47,87-95 rep analysis) of every clip: drains the pipeline, runs both on the
+ * device, then ONE packed copy and ONE stream synchronisation.  Arrays of n_clips entries; phases6 [n_clips][cap][6].  Any of the
+ * output pointers may be NULL (vbt_pipeline_finish = close without the read-back, synchronises too). */
+int vbt_pipeline_close(vbt_pipeline* p, int32_t* best_ids, int32_t* n_rows, int32_t* n_phases, int32_t* overflow, double* phases6, int cap);
+int vbt_pipeline_finish(vbt_pipeline* p);
+/* enqueue every tracker step still held back (deferred groups, the `depth - 1` steps the own-stream mode keeps ahead); no synchronisation */
+int vbt_pipeline_drain(vbt_pipeline* p);
+/* vbt_tracker_rows_all / vbt_tracker_rows / vbt_tracker_phases after draining the pipeline (synchronise) */
+int vbt_pipeline_rows_all(vbt_pipeline* p, int32_t* counts, void* rows_host, int cap);
+int vbt_pipeline_rows(vbt_pipeline* p, int clip, int64_t* id, double* cols7, int cap, int* n);
+/* most recent step's detector outputs copied to host arrays [B,25,4], [B,25], [B,25], [B] (synchronises that forward; tests) */
+int vbt_pipeline_detections(vbt_pipeline* p, float* boxes, float* scores, float* classes, int32_t* counts, int cap_slots, int* B);
+/* measurement split: `count` tracker steps of all clips on the detections sitting in ring slot `slot` */
+int vbt_pipeline_tracker_only_steps(vbt_pipeline* p, int count, int slot);
+typedef struct {
+  int32_t n_slots, n_clips, rows_cap, device, depth, ring, defer, tracker_inline, image_size, frame_count, steps_enqueued, placement_ok;
+  int32_t queue_groups_seen;  /* distinct hardware queues the placement probe has seen on this device */
+  int32_t reserved[3];
+  void* det_streams[8];
+  void* copy_stream;
+  void* tracker_stream;
+  uint64_t h2d_bytes;         /* bytes copied host -> device by this pipeline so far */
+} vbt_pipeline_info;
+int vbt_pipeline_get_info(const vbt_pipeline* p, vbt_pipeline_info* out);
+/* borrowed handles (owned by the pipeline): detector instance k < depth, the tracker */
+vbt_model* vbt_pipeline_model(vbt_pipeline* p, int k);
+vbt_tracker* vbt_pipeline_tracker(vbt_pipeline* p);
+
+/* track(src, interpreter, detection_treshold, ...) of reference track.py:129-260 for ONE clip held in memory: T frames uint8
+ * [T,H,W,3] (host or device; any resolution: src_h/src_w as above, 0 = network resolution), every frame_stride-th frame processed
+ * (track.py:166), `p` created with n_clips = 1; n_slots consecutive kept frames per detector batch.  Returns the clip's rows in
+ * emission order = the dict of track.py:144-145,227-234 (id int64 [n]; cols7 float64 [n,7] = time,x,y,dx,dy,h,w).  Synchronises. */
+int vbt_track_clip(vbt_pipeline* p, const uint8_t* frames, int frames_on_device, int T, int src_h, int src_w, int swap_rb,
+                   int frame_stride, int64_t* id, double* cols7, int cap, int* n_rows);
+
+/* Pinned host memory for callers without a runtime of their own (frames handed to vbt_pipeline_step from it are copied by DMA) */
+int vbt_host_alloc(size_t bytes, void** out);
+int vbt_host_free(void* ptr);
+int vbt_device_alloc(int device, size_t bytes, void** out);
+int vbt_device_free(void* ptr);
+/* blocking copies for the same callers (kind: 0 = host -> device, 1 = device -> host) */
+int vbt_memcpy(void* dst, const void* src, size_t bytes, int kind);
+int vbt_stream_synchronize(void* stream);
+int vbt_device_synchronize(int device);
+
 /* ------------------------------------------------------------------ rep analysis ------------
  * Replaces VelocityTracker (reference VelocityTracker.py:15-230) as driven by analyze_df
  * (reference plot.py:33-47): cols7 [T,7] = time,x,y,dx,dy,norm_plate_height,norm_plate_width

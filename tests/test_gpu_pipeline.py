@@ -1,5 +1,7 @@
 """GPU end-to-end: frames -> detect -> NMS -> OC-SORT -> export id -> rep analysis through the fused
 Pipeline, against the oracle chain on the same seeded frames; plus the odt/track call shapes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -404,3 +406,56 @@ def test_busy_streams_sit_on_distinct_hardware_queues(model_path):
     for i in range(len(busy)):
         for j in range(i + 1, len(busy)):
             assert not shared(busy[i], busy[j]), (i, j)
+
+
+def test_sixty_four_clips_without_torch(model_path, tmp_path):
+    """The pipeline behind the C ABI needs no framework: a child process that never imports torch drives 64 clips through
+    vbt_pipeline_create / _step / _close / _rows_all - frames resident in device memory from vbt_device_alloc, and once more from
+    pinned host memory (vbt_host_alloc) - and its rows, export ids and phases equal those of the same clips driven from this
+    (torch-using) process."""
+    import pickle
+    import subprocess
+    import sys
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    n, T = 64, 6
+    frames = np.stack([np.stack([synth.render(synth.background(300 + c), 3 * c + t) for c in range(n)]) for t in range(T)])
+    src = tmp_path / "frames.npy"
+    np.save(src, frames)
+    code = (
+        "import sys, pickle, numpy as np\n"
+        "from vbt_amd.track import Pipeline\n"
+        "from vbt_amd import mem\n"
+        "frames = np.load(sys.argv[1])\n"
+        "T, n = frames.shape[:2]\n"
+        "out = {}\n"
+        "pipe = Pipeline(sys.argv[2], n, max_frames=T, fps=60.0, rows_per_frame=25)\n"
+        "dev = [mem.DeviceBuffer.from_host(frames[t]) for t in range(T)]\n"
+        "pinned = mem.pinned_empty(frames.shape)\n"
+        "pinned[...] = frames\n"
+        "for name, srcs in (('device', [d.ptr for d in dev]), ('pinned', [pinned[t] for t in range(T)])):\n"
+        "    pipe.reset()\n"
+        "    for t in range(T):\n"
+        "        pipe.step(srcs[t])\n"
+        "    best, rows_n, nph, ovf, ph = pipe.close(cap=16)\n"
+        "    counts, rows = pipe.rows_all()\n"
+        "    out[name] = (best, rows_n, nph, ovf, ph, counts, [rows[c, :counts[c]].tobytes() for c in range(n)])\n"
+        "assert 'torch' not in sys.modules, 'torch was imported'\n"
+        "pickle.dump(out, open(sys.argv[3], 'wb'))\n")
+    dst = tmp_path / "out.pkl"
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    subprocess.run([sys.executable, "-c", code, str(src), model_path, str(dst)], check=True, cwd=root, timeout=300)
+    got = pickle.load(open(dst, "rb"))
+    pipe = Pipeline(model_path, n, max_frames=T, fps=60.0, rows_per_frame=25)
+    fd = torch.from_numpy(frames).to("cuda:0")
+    for t in range(T):
+        pipe.step(fd[t])
+    best, rows_n, nph, ovf, ph = pipe.close(cap=16)
+    counts, rows = pipe.rows_all()
+    assert int(counts.sum()) > 100 and np.all(ovf == 0)
+    for name in ("device", "pinned"):
+        g = got[name]
+        for a, b in zip(g[:6], (best, rows_n, nph, ovf, ph, counts)):
+            assert np.array_equal(a, b), name
+        assert g[6] == [rows[c, :counts[c]].tobytes() for c in range(n)], name

@@ -45,6 +45,9 @@ bool lds_opt_in(const void* fn, LdsOptIn* state);
     }                                                                                    \
   } while (0)
 
+// preprocess_image (reference odt.py:10-19) on device memory (detector.hip); compact != 0: src holds only the row pairs the resize reads
+int resize_frames_dev(const uint8_t* src_dev, int B, int H, int W, uint8_t* dst_dev, int h, int w, int swap_rb, int compact, hipStream_t st);
+
 // ---- VBTM container records (vbt_amd/container.py is the writer) ----
 enum { OP_STEM = 1, OP_PW = 2, OP_DW = 3, OP_ADD = 4, OP_MAXPOOL = 5, OP_RESIZE_NN = 6, OP_POSTPROCESS = 7 };
 

@@ -2744,6 +2744,19 @@ int vbt_stream_destroy(void* stream) {
   return VBT_OK;
 }
 
+}  // extern "C"
+namespace vbt {
+int resize_frames_dev(const uint8_t* src_dev, int B, int H, int W, uint8_t* dst_dev, int h, int w, int swap_rb, int compact, hipStream_t st) {
+  if (compact && H < 2) { set_error("resize: compact rows need a source of at least two rows"); return VBT_ERR_ARG; }
+  const long total = (long)B * h * w;
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  resize_bilinear_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(src_dev, dst_dev, total, H, W, h, w, sy, sx, swap_rb, compact);
+  VBT_HIP_CHECK(hipGetLastError());
+  return VBT_OK;
+}
+}  // namespace vbt
+extern "C" {
+
 int vbt_resize_frames(const uint8_t* src, int B, int H, int W, int src_on_device, uint8_t* dst, int h, int w, int dst_on_device,
                       int swap_rb, int device, void* stream) {
   if (!src || !dst || B < 1 || H < 1 || W < 1 || h < 1 || w < 1) { set_error("vbt_resize_frames: bad argument"); return VBT_ERR_ARG; }
@@ -2767,10 +2780,7 @@ int vbt_resize_frames(const uint8_t* src, int B, int H, int W, int src_on_device
     VBT_HIP_CHECK(hipMalloc((void**)&dd, db));
     dp = dd;
   }
-  long total = (long)B * h * w;
-  float sy = (float)H / (float)h, sx = (float)W / (float)w;
-  resize_bilinear_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(sp, dp, total, H, W, h, w, sy, sx, swap_rb);
-  hipError_t e = hipGetLastError();
+  hipError_t e = resize_frames_dev(sp, B, H, W, dp, h, w, swap_rb, 0, st) == VBT_OK ? hipSuccess : hipErrorLaunchFailure;
   if (e == hipSuccess && !dst_on_device) e = hipMemcpyAsync(dst, dd, db, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess && (ds || dd)) e = hipStreamSynchronize(st);
   if (ds) (void)hipFree(ds);

@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                               long total, int H, int W, int h, int w, float sy, float sx,
-                                                              int swap_rb) {
+                                                              int swap_rb, int compact) {
   long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   int ox = (int)(idx % w);
@@ -1216,7 +1216,14 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint8_t* __r
   int y0 = max((int)fy, 0), y1 = min((int)ceilf(iy), H - 1);
   int x0 = max((int)fx, 0), x1 = min((int)ceilf(ix), W - 1);
   float ly = iy - fy, lx = ix - fx;
-  const uint8_t* s = src + b * (long)H * W * 3;
+  // compact: the source holds only the row pairs the resize reads, [B][2h][W][3]: pair oy = source rows p, p + 1 with p = min(y0, H - 2)
+  // (the host-fed pipeline uploads nothing else, pipeline.hip); y0 and y1 then become rows 2 oy + (y - p)
+  const uint8_t* s = src + b * (long)(compact ? 2 * h : H) * W * 3;
+  if (compact) {
+    const int p = min(y0, H - 2);
+    y0 = 2 * oy + (y0 - p);
+    y1 = 2 * oy + (y1 - p);
+  }
   uint8_t* d = dst + ((b * h + oy) * (long)w + ox) * 3;
 #pragma unroll
   for (int c = 0; c < 3; c++) {

@@ -39,9 +39,20 @@ class Interpreter:
         _lib.check(_lib.lib().vbt_model_input_shape(self._h, shp))
         self._shape = np.array([1, shp[1], shp[2], shp[3]], dtype=np.int32)
 
+    @classmethod
+    def _borrowed(cls, handle, model_path, device, max_batch, owner):
+        """A view of a detector instance owned by a vbt_pipeline (never destroyed from here; `owner` is kept alive)."""
+        self = cls.__new__(cls)
+        self.model_path, self.num_threads, self.device, self.max_batch = str(model_path), 4, device, int(max_batch)
+        self._h, self._owner = ctypes.c_void_p(handle), owner
+        shp = (ctypes.c_int * 4)()
+        _lib.check(_lib.lib().vbt_model_input_shape(self._h, shp))
+        self._shape = np.array([1, shp[1], shp[2], shp[3]], dtype=np.int32)
+        return self
+
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h and _lib is not None and _lib._lib is not None:
+        if h and getattr(self, "_owner", None) is None and _lib is not None and _lib._lib is not None:
             _lib._lib.vbt_model_destroy(h)
             self._h = None
 

@@ -32,9 +32,17 @@ class MultiClipTracker:
         p = _params(det_thresh, max_age, min_hits, iou_threshold, delta_t, asso_func, inertia)
         _lib.check(_lib.lib().vbt_tracker_create(self.n_clips, self.rows_cap, ctypes.byref(p), device, ctypes.byref(self._h)))
 
+    @classmethod
+    def _borrowed(cls, handle, n_clips, rows_cap, owner):
+        """A view of the tracker owned by a vbt_pipeline (never destroyed from here; `owner` is kept alive)."""
+        self = cls.__new__(cls)
+        self.n_clips, self.rows_cap = int(n_clips), int(rows_cap)
+        self._h, self._owner = ctypes.c_void_p(handle), owner
+        return self
+
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h and _lib is not None and _lib._lib is not None:
+        if h and getattr(self, "_owner", None) is None and _lib is not None and _lib._lib is not None:
             _lib._lib.vbt_tracker_destroy(h)
             self._h = None
 
