@@ -497,24 +497,6 @@ def _timed(torch, body, reps=2):
     return best
 
 
-def host_cost_per_step(pipe, fr, fb, U, stream, steps=8):
-    """Host microseconds one Pipeline.step() costs when nothing makes it wait: `steps` calls (fewer than the ring holds) into an idle
-    pipeline, timed on the host, best of 20 rounds - the Python / ctypes / HIP-runtime enqueue cost per step, apart from the GPU's pace."""
-    import torch
-    best = None
-    n = max(1, min(steps, pipe.depth))
-    for _ in range(20):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in range(n):
-            pipe.step(fr.data_ptr() + (t % U) * fb, stream)
-        dt = (time.perf_counter() - t0) / n
-        best = dt if best is None else min(best, dt)
-    torch.cuda.synchronize()
-    pipe.reset()
-    return best * 1e6
-
-
 def other_configs(torch, dev):
     """BASELINE.json configs 2, 4 and 5 and the small-batch points, each as whole-clip runs (clip close + rows on the host
     inside the timed region), frames resident in HBM."""
@@ -549,12 +531,14 @@ def other_configs(torch, dev):
             pipe.rows_all()
         dt = _timed(torch, body)
         fps = nb * T / dt
-        # enqueue_ms: host time inside the T step() calls of a run (they return as soon as the work is queued; the host blocks only on the
-        # back-pressure of a full ring).  enqueue_us_per_step against ms_per_step says whether the host or the GPU paces the run; the host's own
-        # cost per step is measured with the GPU out of the way: detector-only steps into an idle, 1-deep queue cannot be isolated, so it is
-        # the minimum over the runs of (enqueue time / steps), which is the GPU's pace when the host is NOT the limiter.
+        # enqueue_ms: host time inside the T step() calls of a run (they return as soon as the work is queued; the host blocks only on back-pressure
+        # from the HIP runtime's queues).  library_us_per_step is the part of it spent inside vbt_pipeline_step (vbt_pipeline_info.step_host_ns,
+        # last run), the rest is the Python / ctypes wrapper.  enqueue_us_per_step well below ms_per_step = the GPU, not the host, paces the run.
+        inf = pipe.info()
+        lib_us = inf.step_host_ns / max(inf.step_calls, 1) / 1e3
         return {"frames_per_s": fps, "ms_per_step": dt / T * 1e3, "batch": nb, "frames_per_clip": T, "roofline_frac_8d": roofline_frac_8d(fps, 0, nb),
-                "enqueue_ms": min(enq) * 1e3, "enqueue_us_per_step": min(enq) / T * 1e6, "host_us_per_step_unblocked": host_cost_per_step(pipe, fr, fb, U, stream),
+                "enqueue_ms": min(enq) * 1e3, "enqueue_us_per_step": min(enq) / T * 1e6, "library_us_per_step": lib_us,
+                "wrapper_us_per_step": enq[-1] / T * 1e6 - lib_us, "host_paces_the_run": bool(min(enq) > 0.9 * dt),
                 "note": f"{nb} clip(s), one frame per clip per step (the forward is a replayed hipGraph), {pipe.depth} forwards in flight"}
     guarded("b1", lambda: small_batch(1, 2048))
     guarded("b8", lambda: small_batch(8, 1024))
@@ -742,12 +726,19 @@ def other_configs(torch, dev):
             dt = _timed(torch, body)
             res[name] = {"frames_per_s": nb * T / dt, "ms_per_step": dt / T * 1e3}
         bytes_step = nb * H * W * 3
+        up0 = pipe.info().h2d_bytes
+        pipe.reset()
+        pipe.step(host_src[0], stream, src_hw=(H, W), swap_rb=True)
+        pipe.close(cap=64)
+        uploaded = int(pipe.info().h2d_bytes - up0)               # only the row pairs the bilinear resize reads travel (vbt_amd/csrc/pipeline.hip)
         return {"frames_per_s": res["host_fed"]["frames_per_s"], "resident_frames_per_s": res["resident"]["frames_per_s"],
                 "ms_per_step": res["host_fed"]["ms_per_step"], "resident_ms_per_step": res["resident"]["ms_per_step"], "batch": nb,
-                "source_hw": [H, W], "h2d_bytes_per_step": bytes_step, "h2d_GBps": bytes_step / (res["host_fed"]["ms_per_step"] * 1e-3) / 1e9,
+                "source_hw": [H, W], "source_bytes_per_step": bytes_step, "h2d_bytes_per_step": uploaded,
+                "h2d_GBps": uploaded / (res["host_fed"]["ms_per_step"] * 1e-3) / 1e9,
                 "roofline_frac_8d": roofline_frac_8d(res["host_fed"]["frames_per_s"], 0, nb),
-                "note": "64 uint8 1920x1080x3 BGR frames per step (398 MB): host-fed = pinned host memory -> H2D -> resize on the device -> detect + "
-                        "NMS + track (PCIe-bound: 6.2 MB per frame); resident = the same frames already in HBM"}
+                "note": "64 uint8 1920x1080x3 BGR frames per step (398 MB in host memory): host-fed = pinned host memory -> H2D of the 2 x 320 source rows per frame "
+                        "the bilinear resize of odt.py:15-16 reads (one strided copy, a third of the bytes) -> resize on the device -> detect + NMS + track; "
+                        "resident = the same frames already in HBM"}
     guarded("n2_1080x1920", n2_source)
 
     # ---- config 4: EfficientDet-Lite2 448x448 + OC-SORT, 64 clips per step ----

@@ -278,6 +278,8 @@ typedef struct {
   void* copy_stream;
   void* tracker_stream;
   uint64_t h2d_bytes;         /* bytes copied host -> device by this pipeline so far */
+  uint64_t step_host_ns;      /* host time spent inside vbt_pipeline_step / _step_runs so far (enqueue cost incl. any back-pressure wait) */
+  uint64_t step_calls;        /* ... over this many calls (both zeroed by vbt_pipeline_reset) */
 } vbt_pipeline_info;
 int vbt_pipeline_get_info(const vbt_pipeline* p, vbt_pipeline_info* out);
 /* borrowed handles (owned by the pipeline): detector instance k < depth, the tracker */

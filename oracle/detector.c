@@ -21,7 +21,8 @@
  *     src = min(floor(dst * (float)in / out), in - 1), the product evaluated in float32;
  *   - LOGISTIC (XNNPACK x8-lut): table lrintf(256 / (1 + expf(-s_x (i - z_x)))) - 128 in float32;
  *   - DEQUANTIZE: one float32 multiplication s * (q - z);
- *   - TFLite_Detection_PostProcess (TFLite builtin detection_postprocess.cc, fast single-class path):
+ *   - TFLite_Detection_PostProcess (TFLite builtin detection_postprocess.cc, NonMaxSuppressionMultiClassFastHelper with
+ *     max_classes_per_detection = 1: the best class column of every anchor, then single-class NMS on those scores):
  *     centre-size decode evaluated in double and rounded to float once per quantity, score filter
  *     (>=), stable descending sort, greedy IoU (> threshold) suppression, top-25.
  * PARITY UNPINNED for this file: the reference holds no model, no input frame and no golden
@@ -46,7 +47,9 @@ typedef struct {
   int32_t arch, image_size, num_tensors, num_ops, num_anchors, max_detections;
   float nms_iou_threshold, nms_score_threshold;
   int64_t blob_offset, blob_bytes;
-  int32_t input_tensor, reserved[17];
+  int32_t input_tensor;
+  int32_t num_classes; /* class columns per anchor of the head's class tensors (0 in older files = 1) */
+  int32_t reserved[16];
 } hdr_t;
 typedef struct { int32_t h, w, c, zero_point; float scale; int32_t pad[3]; } tens_t;
 typedef struct {
@@ -375,13 +378,26 @@ static int run_postprocess(vbto_model* m, const op_t* op, float* boxes, float* s
     if (m->tensors[op->inputs[l]].scale != tc->scale || m->tensors[op->inputs[l]].zero_point != tc->zero_point ||
         m->tensors[op->inputs[nl + l]].scale != tb->scale || m->tensors[op->inputs[nl + l]].zero_point != tb->zero_point)
       return -3;
-  int8_t* cls = (int8_t*)malloc(A);
+  /* class predictions [A][C] (C = num_classes_with_background of detection_postprocess.cc; the op's num_classes equals it for the
+   * reference's models, label_offset = 0).  NonMaxSuppressionMultiClassFastHelper with max_classes_per_detection = 1: per anchor the
+   * best class by DecreasingPartialArgSort(.., 1) = ArgMaxVector on the float scores = the FIRST column holding the highest score
+   * (two class bytes on a plateau of the LOGISTIC table are one score), then single-class NMS on those best scores. */
+  const int C = m->hdr.num_classes > 0 ? m->hdr.num_classes : 1;
+  int8_t* cls = (int8_t*)malloc((size_t)A);          /* class byte of the best column */
+  int32_t* cid = (int32_t*)malloc(sizeof(int32_t) * (size_t)A);
   int8_t* box = (int8_t*)malloc((size_t)A * 4);
   size_t o = 0;
   for (int l = 0; l < nl; l++) { /* RESHAPE + CONCATENATION of the per-level head outputs */
     const tens_t* t = &m->tensors[op->inputs[l]];
-    size_t n = (size_t)t->h * t->w * t->c;
-    memcpy(cls + o, m->data[op->inputs[l]], n);
+    size_t n = (size_t)t->h * t->w * t->c / (size_t)C; /* anchors of the level */
+    const int8_t* src = m->data[op->inputs[l]];
+    for (size_t a = 0; a < n; a++) {
+      int best = 0;
+      for (int c = 1; c < C; c++)
+        if (score_lut[src[a * C + c] + 128] > score_lut[src[a * C + best] + 128]) best = c;
+      cls[o + a] = src[a * C + best];
+      cid[o + a] = best;
+    }
     memcpy(box + o * 4, m->data[op->inputs[nl + l]], n * 4);
     o += n;
   }
@@ -411,7 +427,7 @@ static int run_postprocess(vbto_model* m, const op_t* op, float* boxes, float* s
     sel[ns] = b;
     boxes[ns * 4 + 0] = b.ymin; boxes[ns * 4 + 1] = b.xmin; boxes[ns * 4 + 2] = b.ymax; boxes[ns * 4 + 3] = b.xmax;
     scores[ns] = score_lut[cand[j].q + 128];
-    classes[ns] = 0.0f;
+    classes[ns] = (float)cid[i];
     ns++;
   }
   for (int s = ns; s < maxdet; s++) {
@@ -419,7 +435,7 @@ static int run_postprocess(vbto_model* m, const op_t* op, float* boxes, float* s
     scores[s] = 0.0f; classes[s] = 0.0f;
   }
   *count = ns;
-  free(cand); free(cls); free(box);
+  free(cand); free(cls); free(cid); free(box);
   return 0;
 }
 

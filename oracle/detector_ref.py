@@ -11,7 +11,8 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(os.path.join(_HERE, "libvbt_oracle.so"))
+        # VBT_ORACLE_LIB: the sanitizer build of the same source (make -C oracle asan; tests/test_oracle_asan.py)
+        L = ctypes.CDLL(os.environ.get("VBT_ORACLE_LIB") or os.path.join(_HERE, "libvbt_oracle.so"))
         L.vbto_load.restype = ctypes.c_void_p
         L.vbto_load.argtypes = [ctypes.c_char_p]
         L.vbto_free.argtypes = [ctypes.c_void_p]

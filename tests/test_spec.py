@@ -5,13 +5,31 @@ import pytest
 from vbt_amd import spec
 
 
-@pytest.mark.parametrize("arch,macs_m,log_macs_m,anchors", [(0, 864.2, 876.0, 19206), (1, 1750.3, 1773.0, 27621), (2, 2996.2, 3033.0, 37629)])
-def test_mac_and_anchor_counts(arch, macs_m, log_macs_m, anchors):
+LOG_OPS = {0: ("efficientdet_lite0_whole.log", "1.752", "0.876"), 1: ("efficientdet_lite1_whole.log", "3.547", "1.773"), 2: ("efficientdet_lite2.log", "6.066", "3.033")}
+
+
+@pytest.mark.parametrize("arch,macs_m,anchors", [(0, 865.4, 19206), (1, 1752.8, 27621), (2, 3000.4, 37629)])
+def test_graph_reproduces_the_converters_op_counts(arch, macs_m, anchors):
+    """The one reference-held number that constrains the detector graph (A4-A6): the TFLite converter's "Estimated count of arithmetic
+    ops: 1.752 G ops, equivalently 0.876 G MACs" (reference models/efficientdet_lite0_whole.log:110; Lite1 3.547 / 1.773, Lite2
+    6.066 / 3.033).  Under the converter's counting rule (Graph.tflite_arithmetic_ops) the restated graph gives all six printed figures
+    to the last digit - with the class net the model maker builds for `label_map={1: "barbell"}` (train.py:30-46): two class columns per
+    anchor.  A one-column class net (rounds 1-4) misses every one of them by the same 0.2 %: that was the unresolved residual of
+    SURVEY.md 8a (its -1.3 % compared MACs with the converter's ops / 2, which also count bias adds, ADDs, pools and LOGISTIC)."""
     g = spec.build_graph(arch)
+    assert g.num_classes == 2
+    ops = g.tflite_arithmetic_ops()
+    name, want_ops, want_macs = LOG_OPS[arch]
+    assert f"{ops / 1e9:.3f}" == want_ops and f"{ops / 2e9:.3f}" == want_macs
+    one = spec.build_graph(arch, num_classes=1).tflite_arithmetic_ops()
+    assert f"{one / 1e9:.3f}" != want_ops and 0.997 < one / ops < 0.999
     assert round(g.total_macs() / 1e6, 1) == macs_m
-    # reference models/efficientdet_lite*_whole.log:110 prints 2*MACs as "ops"; our restatement sits 1.2-1.4% below it
-    assert 0.98 < g.total_macs() / 1e6 / log_macs_m < 1.0
     assert g.num_anchors() == anchors == len(spec.make_anchors(arch))
+    import os
+    log = os.path.join("/root/reference/models", name)           # (the reference tree is not on the GPU box; this is a CPU-suite check)
+    if os.path.exists(log):
+        line = [ln for ln in open(log, errors="replace").read().replace("\r", "\n").split("\n") if "Estimated count of arithmetic ops" in ln][0]
+        assert f"{want_ops} G  ops" in line and f"{want_macs} G  MACs" in line
 
 
 def test_lite0_op_inventory():
@@ -22,7 +40,7 @@ def test_lite0_op_inventory():
     # 24 BiFPN sums (9 of them 3-input = two chained binary ADDs, like the converter's graph) + 9 MBConv residual adds
     assert c["add"] == 24 + 9 + 9 and c["maxpool"] + c["resize"] == 24 + 2
     stages = {st: sum(o.macs(g.tensors) for o in g.ops if o.stage == st) / 1e6 for st in ("backbone", "fpn", "head")}
-    assert [round(stages[k], 1) for k in ("backbone", "fpn", "head")] == [742.5, 53.2, 68.4]
+    assert [round(stages[k], 1) for k in ("backbone", "fpn", "head")] == [742.5, 53.2, 69.7]     # (SURVEY 8a's 68.4 is the one-class head)
     p = {g.tensors[o.output].name: g.tensors[o.output] for o in g.ops}
     assert (p["b4.skip"].h, p["b4.skip"].c) == (40, 40) and (p["b10.skip"].h, p["b10.skip"].c) == (20, 112) and (p["b15.project"].h, p["b15.project"].c) == (10, 320)
 

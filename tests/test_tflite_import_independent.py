@@ -154,14 +154,18 @@ def test_oracle_on_imported_graph_equals_numpy_evaluation_of_the_source_model(ti
         for name, store, zo in (("class", cls, 12), ("box", box, -7)):
             me = m.meta[f"{name}{li}"]
             store.append(_requant(_conv(t, me["w"], me["b"], -128, 1, 0, 0, t.shape[0]), mul(me), zo, -128, 127).reshape(-1))
-    cls, box = np.concatenate(cls), np.concatenate(box).reshape(-1, 4)
+    cls, box = np.concatenate(cls).reshape(-1, m.num_classes), np.concatenate(box).reshape(-1, 4)
+    assert m.num_classes == 2
     # LOGISTIC (float32 table) -> DEQUANTIZE -> decode in double -> fast NMS, all from the source model's numbers
     sig = np.asarray([min(max(f32(256.0) / (f32(1.0) + f32(math.exp(-float(f32(0.09) * f32(int(q) - 12))))), f32(0)), f32(255)) for q in range(-128, 128)], f32)
     score = (np.rint(sig).astype(np.int64)).astype(f32) * f32(1 / 256)
-    sc = score[cls.astype(int) + 128]
+    # two class columns per anchor: the anchor scores with its best column, its class is the first column holding that score
+    col_sc = score[cls.astype(int) + 128]                                                 # [A, 2]
+    sc = col_sc.max(axis=1)
+    best_col = np.argmax(col_sc, axis=1)
     order = sorted([i for i in range(len(cls)) if sc[i] >= f32(0.0625)], key=lambda i: (-sc[i], i))
     bq = (f32(0.021) * (box.astype(np.int64) + 7).astype(f32)).astype(f32)
-    sel = []
+    sel, sel_cls = [], []
     for i in order:
         an = m.anchors[i].astype(np.float64)
         yc, xc = f32(float(bq[i, 0]) / 10.0 * an[2] + an[0]), f32(float(bq[i, 1]) / 10.0 * an[3] + an[1])
@@ -177,9 +181,11 @@ def test_oracle_on_imported_graph_equals_numpy_evaluation_of_the_source_model(ti
                 break
         if ok:
             sel.append((b, sc[i]))
+            sel_cls.append(float(best_col[i]))
         if len(sel) == 25:
             break
     assert count == len(sel) and count > 3
+    assert classes[:count].tolist() == sel_cls and 0 < sum(sel_cls) < count               # both columns win somewhere
     assert np.array_equal(scores[:count], np.asarray([s for _, s in sel], f32))
     assert np.array_equal(boxes[:count], np.stack([b for b, _ in sel]))
 

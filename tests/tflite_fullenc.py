@@ -121,7 +121,8 @@ class ConverterStyleModel(TinyModel):
             elif n["kind"] == "resize":
                 n["st"] = self.tensor(f"efficientdet-lite/resize_{i}/size", [2], TT_INT32, buffer=self.buf(n["size"]))
         r, pins = post
-        levels = {"class": (pins[:5], 1), "box": (pins[5:], 4)}
+        NC = max(int(c.header["num_classes"]), 1)          # class columns per anchor
+        levels = {"class": (pins[:5], NC), "box": (pins[5:], 4)}
         shape_t = {}
         for name, (lv, width) in levels.items():
             for li, t in enumerate(lv):
@@ -163,7 +164,7 @@ class ConverterStyleModel(TinyModel):
             cat = self.tensor(f"{name}_net/concat", [1, A, width], TT_INT8, [f32(q["scale"])], [int(q["zero_point"])])
             self.op(BO_CONCATENATION, parts, [cat], 10, {0: S("i", 1)})
             if name == "class":
-                lg = self.tensor("class_net/Sigmoid", [1, A, 1], TT_INT8, [f32(1 / 256)], [-128])
+                lg = self.tensor("class_net/Sigmoid", [1, A, NC], TT_INT8, [f32(1 / 256)], [-128])
                 self.op(BO_LOGISTIC, [cat], [lg])
                 cat = lg
             dq = self.tensor(f"{name}_net/dequantize", [1, A, width], TT_FLOAT32)
@@ -173,7 +174,7 @@ class ConverterStyleModel(TinyModel):
                                                                ("StatefulPartitionedCall:1", [1, 25]), ("StatefulPartitionedCall:0", [1]))]
         self.options = {"max_detections": int(c.header["max_detections"]), "max_classes_per_detection": 1, "detections_per_class": 100,
                         "use_regular_nms": False, "nms_score_threshold": float(c.header["nms_score_threshold"]),
-                        "nms_iou_threshold": float(c.header["nms_iou_threshold"]), "num_classes": 1,
+                        "nms_iou_threshold": float(c.header["nms_iou_threshold"]), "num_classes": NC,
                         "y_scale": 1.0, "x_scale": 1.0, "h_scale": 1.0, "w_scale": 1.0}
         self.op(BO_CUSTOM, [cats["box"], cats["class"], at], outs, custom="TFLite_Detection_PostProcess", custom_options=flexbuffer_map(self.options))
         self.image, self.outputs, self.n_ops_native, self.order = tid["img"], outs, len(nodes), order

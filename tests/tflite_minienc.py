@@ -194,9 +194,10 @@ class TinyModel:
     P4..P7 = MAX_POOL 3x3/2 chain; per level class conv 1x1 8->9 and box conv 1x1 8->36 with weights / bias SHARED across
     levels (one buffer, five tensors); RESHAPE, CONCATENATION, LOGISTIC, DEQUANTIZE, TFLite_Detection_PostProcess."""
 
-    def __init__(self, S=32, seed=5):
+    def __init__(self, S=32, seed=5, num_classes=2):
         rng = np.random.default_rng(seed)
         self.S = S
+        self.num_classes = int(num_classes)       # class columns per anchor (the reference's models: 2, vbt_amd/spec.py)
         self.rng = rng
         self.tensors, self.buffers, self.ops, self.codes = [], [np.zeros(0, np.uint8)], [], []
         self.meta = {}
@@ -259,7 +260,8 @@ class TinyModel:
         self.level_h = [self.tensors[t]["shape"][1] for t in levels]
         cats = []
         n_anchor = sum(x * x for x in self.level_h) * 9
-        for name, cout, width, s_out, z_out in (("class", 9, 1, f32(0.09), 12), ("box", 36, 4, f32(0.021), -7)):
+        NC = self.num_classes
+        for name, cout, width, s_out, z_out in (("class", 9 * NC, NC, f32(0.09), 12), ("box", 36, 4, f32(0.021), -7)):
             parts, shared = [], None
             for li, t in enumerate(levels):
                 hh = self.level_h[li]
@@ -271,7 +273,7 @@ class TinyModel:
             cat = self.tensor(f"{name}/concat", [1, n_anchor, width], TT_INT8, [s_out], [z_out])
             self.op(BO_CONCATENATION, parts, [cat], 10, {0: S("i", 1)})                  # ConcatenationOptions.axis:0
             if name == "class":
-                lg = self.tensor("class/logistic", [1, n_anchor, 1], TT_INT8, [f32(1 / 256)], [-128])
+                lg = self.tensor("class/logistic", [1, n_anchor, NC], TT_INT8, [f32(1 / 256)], [-128])
                 self.op(BO_LOGISTIC, [cat], [lg])
                 cat = lg
             dq = self.tensor(f"{name}/dequantize", [1, n_anchor, width], TT_FLOAT32)
@@ -282,7 +284,7 @@ class TinyModel:
         outs = [self.tensor(n, s, TT_FLOAT32) for n, s in (("StatefulPartitionedCall:3", [1, 25, 4]), ("StatefulPartitionedCall:2", [1, 25]),
                                                            ("StatefulPartitionedCall:1", [1, 25]), ("StatefulPartitionedCall:0", [1]))]
         self.options = {"max_detections": 25, "max_classes_per_detection": 1, "detections_per_class": 100, "use_regular_nms": False,
-                        "nms_score_threshold": 0.0625, "nms_iou_threshold": 0.45, "num_classes": 1,
+                        "nms_score_threshold": 0.0625, "nms_iou_threshold": 0.45, "num_classes": NC,
                         "y_scale": 10.0, "x_scale": 10.0, "h_scale": 5.0, "w_scale": 5.0}
         self.op(BO_CUSTOM, [cats[1], cats[0], at], outs, custom="TFLite_Detection_PostProcess", custom_options=flexbuffer_map(self.options))
         self.anchors, self.n_anchor, self.image, self.outputs = anchors, n_anchor, img, outs

@@ -177,8 +177,9 @@ class Exporter:
 
         r, ins = post
         A = int(c.header["num_anchors"])
+        NC = max(int(c.header["num_classes"]), 1)          # class columns per anchor
         branches = []
-        for name, levels, width in (("class", ins[:5], 1), ("box", ins[5:], 4)):
+        for name, levels, width in (("class", ins[:5], NC), ("box", ins[5:], 4)):
             parts = []
             q = T[levels[0]]
             for li, t in enumerate(levels):
@@ -190,7 +191,7 @@ class Exporter:
             cat = self.tensor(f"{name}/concat", [1, A, width], TT_INT8, q["scale"], int(q["zero_point"]))
             self.op(BO_CONCATENATION, parts, [cat], OPT_CONCAT, TableSpec({0: Scalar("i", 1)}))
             if name == "class":
-                lg = self.tensor("class/logistic", [1, A, 1], TT_INT8, np.float32(1.0 / 256.0), -128)
+                lg = self.tensor("class/logistic", [1, A, NC], TT_INT8, np.float32(1.0 / 256.0), -128)
                 self.op(BO_LOGISTIC, [cat], [lg])
                 cat = lg
             dq = self.tensor(f"{name}/dequantize", [1, A, width], TT_FLOAT32)
@@ -203,7 +204,7 @@ class Exporter:
         fo = flex_map({"max_detections": int(c.header["max_detections"]), "max_classes_per_detection": 1,
                        "detections_per_class": 100, "use_regular_nms": False,
                        "nms_score_threshold": float(c.header["nms_score_threshold"]),
-                       "nms_iou_threshold": float(c.header["nms_iou_threshold"]), "num_classes": 1,
+                       "nms_iou_threshold": float(c.header["nms_iou_threshold"]), "num_classes": NC,
                        "y_scale": 1.0, "x_scale": 1.0, "h_scale": 1.0, "w_scale": 1.0})
         self.op(BO_CUSTOM, [branches[1], branches[0], at], outs, custom=POSTPROCESS_NAME, custom_options=fo)
 

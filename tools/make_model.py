@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--calib", type=int, default=8)
     ap.add_argument("--pos_frac", type=float, default=1e-4, help="fraction of anchors with score >= 0.5")
     ap.add_argument("--nms_score_threshold", type=float, default=1.0 / 256)
+    ap.add_argument("--num_classes", type=int, default=spec.NUM_CLASSES, help="class columns per anchor (the reference's models: 2, vbt_amd/spec.py)")
     ap.add_argument("--tie_adds", action="store_true",
                     help="test model: force every ADD's input/output scale ratios to exactly 0.5 or 1.0, so that the integer "
                          "rounding of XNNPACK's qs8-vadd (half towards +infinity) is hit on about half of all elements")
@@ -60,7 +61,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
 
-    g = spec.build_graph(args.arch)
+    g = spec.build_graph(args.arch, args.num_classes)
     S = g.cfg.image_size
     rng = np.random.Generator(np.random.PCG64(1))
     rngn = np.random.Generator(np.random.PCG64(2))      # BN-like targets
@@ -156,7 +157,8 @@ def main():
             pass
 
     # ---- class bias so that pos_frac of the anchors score >= 0.5 on the calibration frames
-    cls_logits = np.concatenate([val[g.ops[oi].output].numpy().reshape(-1) for oi in last_head["cls"]])
+    # (per anchor the post-process scores the best of its class columns: channel = anchor_in_location * num_classes + class)
+    cls_logits = np.concatenate([val[g.ops[oi].output].permute(0, 2, 3, 1).numpy().reshape(-1, g.num_classes).max(axis=1) for oi in last_head["cls"]])
     cls_bias = -float(np.quantile(cls_logits, 1.0 - args.pos_frac))
     for oi in last_head["cls"]:
         fb[oi] = fb[oi] + cls_bias
@@ -271,7 +273,7 @@ def main():
             sb, zb = tq[op.inputs[5]]
             r["aux2_off"] = blob.add(quant.pack_postprocess_tables(sc, zc, sb, zb))     # LOGISTIC / DEQUANTIZE / decode tables
     header = dict(arch=args.arch, image_size=S, num_anchors=g.num_anchors(), max_detections=spec.MAX_DETECTIONS,
-                  nms_iou_threshold=0.5, nms_score_threshold=args.nms_score_threshold, input_tensor=0)
+                  nms_iou_threshold=0.5, nms_score_threshold=args.nms_score_threshold, input_tensor=0, num_classes=g.num_classes)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     write_container(args.out, header, tensors, ops, blob.bytes())
     # report

@@ -43,7 +43,7 @@ class PipelineInfo(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ("n_slots", "n_clips", "rows_cap", "device", "depth", "ring", "defer", "tracker_inline", "image_size",
                                                "frame_count", "steps_enqueued", "placement_ok", "queue_groups_seen")] + \
                [("reserved", ctypes.c_int32 * 3), ("det_streams", c_void_p * 8), ("copy_stream", c_void_p), ("tracker_stream", c_void_p),
-                ("h2d_bytes", ctypes.c_uint64)]
+                ("h2d_bytes", ctypes.c_uint64), ("step_host_ns", ctypes.c_uint64), ("step_calls", ctypes.c_uint64)]
 
 
 class KernelStat(ctypes.Structure):

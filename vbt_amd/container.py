@@ -24,7 +24,9 @@ HEADER_DTYPE = np.dtype([
     ("magic", "S8"), ("arch", "<i4"), ("image_size", "<i4"), ("num_tensors", "<i4"), ("num_ops", "<i4"),
     ("num_anchors", "<i4"), ("max_detections", "<i4"), ("nms_iou_threshold", "<f4"),
     ("nms_score_threshold", "<f4"), ("blob_offset", "<i8"), ("blob_bytes", "<i8"),
-    ("input_tensor", "<i4"), ("reserved", "<i4", (17,)),
+    ("input_tensor", "<i4"),
+    ("num_classes", "<i4"),        # class columns per anchor in the head's class tensors (0 in files written before the field existed = 1)
+    ("reserved", "<i4", (16,)),
 ])
 assert HEADER_DTYPE.itemsize == 128
 

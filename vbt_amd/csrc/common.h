@@ -11,6 +11,7 @@
 
 #include "../../include/vbt_hip.h"
 #include "../../include/vbt_hip_diag.h"
+#include "container_parse.h"
 
 namespace vbt {
 
@@ -48,36 +49,8 @@ bool lds_opt_in(const void* fn, LdsOptIn* state);
 // preprocess_image (reference odt.py:10-19) on device memory (detector.hip); compact != 0: src holds only the row pairs the resize reads
 int resize_frames_dev(const uint8_t* src_dev, int B, int H, int W, uint8_t* dst_dev, int h, int w, int swap_rb, int compact, hipStream_t st);
 
-// ---- VBTM container records (vbt_amd/container.py is the writer) ----
-enum { OP_STEM = 1, OP_PW = 2, OP_DW = 3, OP_ADD = 4, OP_MAXPOOL = 5, OP_RESIZE_NN = 6, OP_POSTPROCESS = 7 };
-
-#pragma pack(push, 1)
-struct Header {
-  char magic[8];
-  int32_t arch, image_size, num_tensors, num_ops, num_anchors, max_detections;
-  float nms_iou_threshold, nms_score_threshold;
-  int64_t blob_offset, blob_bytes;
-  int32_t input_tensor, reserved[17];
-};
-struct TensorRec {
-  int32_t h, w, c, zero_point;
-  float scale;
-  int32_t pad[3];
-};
-struct OpRec {
-  int32_t type, n_inputs, inputs[12], output, k, stride, pad_t, pad_l, act_min, act_max, level;
-  int64_t w_off, b_off, m_off, aux_off, aux2_off;
-  float in_mult[3];      // ADD: s_a/s_out, s_b/s_out (informational)
-  int32_t add_q[4];      // ADD: bias, a_multiplier, b_multiplier, shift (XNNPACK qs8-vadd)
-  int32_t reserved[1];
-};
-#pragma pack(pop)
-static_assert(sizeof(Header) == 128, "header");
-static_assert(sizeof(TensorRec) == 32, "tensor");
-static_assert(sizeof(OpRec) == 160, "op");
-#define VBT_CONTAINER_MAGIC "VBTM0002"
-#define VBT_POST_TABLE_BYTES (256 * 4 * 2 + 256 * 8 * 2 + 16)   // score f32 | box f32 | dq f64 | ex f64 | scales f32[4]
-
+// ---- VBTM container records, reader + validator, plan-file reader: container_parse.h (pure C++, also built host-only under
+// -fsanitize=address,undefined by tests/test_parser_fuzz.py) ----
 // Integer parameters of an int8 ADD exactly as XNNPACK derives them (xnn_create_add_nd_qs8 +
 // xnn_init_qs8_add_minmax_*_params of the XNNPACK revision tflite-runtime 2.14 builds; the reference runs that kernel
 // through the default delegate, reference odt.py:58-61):  q = clamp(((bias + a*am + b*bm) >> shift) + z_out, lo, hi).

@@ -2152,12 +2152,13 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
     case F_POST: {
       PostArgs p;
       int base = 0;
+      p.C = m->hdr.num_classes > 0 ? m->hdr.num_classes : 1;
       for (int l = 0; l < 5; l++) {
         const TensorRec& tc = m->tensors[op.inputs[l]];
         p.cls[l] = TP(op.inputs[l]);
         p.box[l] = TP(op.inputs[5 + l]);
         p.base[l] = base;
-        base += tc.h * tc.w * tc.c;
+        base += tc.h * tc.w * tc.c / p.C;
       }
       p.base[5] = base;
       p.anchors = m->d_anchors;
@@ -2220,6 +2221,44 @@ static double time_step(vbt_model* m, const Step& s, int B, int reps) {
 }
 
 // Plan-time autotuning: every alternative computes bit-identical tensors, so only speed is at stake.
+// Kernel variants the planner offers for a step: what the autotuner times, and all a plan file may select (anything else in a file
+// refuses the file: load_plan).  -1 = the launcher's own default.
+static std::vector<int> candidate_variants(const vbt_model* m, const Step& st) {
+  std::vector<int> cand{-1};
+  const OpRec& op = m->ops[st.op];
+  if (st.family == F_DW) {
+    cand = {0};
+    for (int r : {1, 2, 4, 8, 16})
+      if (r <= m->tensors[op.output].h) cand.push_back(r);
+    if (m->tensors[op.output].c % 8 == 0) { cand.push_back(100); cand.push_back(101); }
+  } else if (st.family == F_PW && st.KS64 <= 4) {
+    cand = {0, 1};
+  } else if (st.family == F_PW) {
+    cand = {-1, 2, 3, 4};
+  } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
+    cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
+    if (image_geom(m, st).ok) cand.push_back(5);  // one workgroup per image
+    if (st.family == F_MBCONV && st.fa.nch3 > 0 && st.nbp <= 2 && st.fa.KSe >= 1 && st.fa.KSe <= 4) { cand.push_back(9); cand.push_back(11); }  // 48-channel chunks
+    if (st.family == F_MBCONV && st.nbp <= 2 && (st.fa.KSe == 1 || st.fa.KSe == 2) && ppw2_fits(m, st)) {   // 128-pixel tiles
+      cand.push_back(17);
+      if (st.fa.nch3 > 0) cand.push_back(25);
+    }
+  } else if (st.family == F_MULTI) {
+    cand = {0, 1};
+  } else if (st.family == F_EXPDW) {
+    cand.clear();
+    for (int cpw : {1, 2, 3, 4, 6})
+      if (cpw <= st.xd.nchunks) cand.push_back(cpw);
+    if (st.xd2_ok)
+      for (int cpw : {1, 2, 3, 4, 6})
+        if (cpw <= st.xd.nchunks) {
+          if (st.xd2_gpw > 0) cand.push_back(100 + cpw);
+          if (st.xd2_gpw16 > 0) cand.push_back(200 + cpw);
+        }
+  }
+  return cand;
+}
+
 static void autotune(vbt_model* m) {
   const int B = (m->max_batch + m->n_sub - 1) / m->n_sub, reps = 4;  // the batch one stream actually sees
   for (Group& g : m->groups) {
@@ -2231,38 +2270,7 @@ static void autotune(vbt_model* m) {
     for (Alt& a : g.alts) {
       a.ms = 0;
       for (Step& st : a.steps) {
-        std::vector<int> cand{-1};
-        const OpRec& op = m->ops[st.op];
-        if (st.family == F_DW) {
-          cand = {0};
-          for (int r : {1, 2, 4, 8, 16})
-            if (r <= m->tensors[op.output].h) cand.push_back(r);
-          if (m->tensors[op.output].c % 8 == 0) { cand.push_back(100); cand.push_back(101); }
-        } else if (st.family == F_PW && st.KS64 <= 4) {
-          cand = {0, 1};
-        } else if (st.family == F_PW) {
-          cand = {-1, 2, 3, 4};
-        } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
-          cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
-          if (image_geom(m, st).ok) cand.push_back(5);  // one workgroup per image
-          if (st.family == F_MBCONV && st.fa.nch3 > 0 && st.nbp <= 2 && st.fa.KSe >= 1 && st.fa.KSe <= 4) { cand.push_back(9); cand.push_back(11); }  // 48-channel chunks
-          if (st.family == F_MBCONV && st.nbp <= 2 && (st.fa.KSe == 1 || st.fa.KSe == 2) && ppw2_fits(m, st)) {   // 128-pixel tiles
-            cand.push_back(17);
-            if (st.fa.nch3 > 0) cand.push_back(25);
-          }
-        } else if (st.family == F_MULTI) {
-          cand = {0, 1};
-        } else if (st.family == F_EXPDW) {
-          cand.clear();
-          for (int cpw : {1, 2, 3, 4, 6})
-            if (cpw <= st.xd.nchunks) cand.push_back(cpw);
-          if (st.xd2_ok)
-            for (int cpw : {1, 2, 3, 4, 6})
-              if (cpw <= st.xd.nchunks) {
-                if (st.xd2_gpw > 0) cand.push_back(100 + cpw);
-                if (st.xd2_gpw16 > 0) cand.push_back(200 + cpw);
-              }
-        }
+        const std::vector<int> cand = candidate_variants(m, st);
         double best = 1e30;
         int bestv = -1;
         for (int v : cand) {
@@ -2312,47 +2320,41 @@ static void autotune(vbt_model* m) {
 // refused and the plan re-tuned.  Format 1 ("<ngroups>" then "<chosen> <nsteps> <variant>...") is still read - the group and step
 // counts are all it can be checked against - and re-written in format 2 when VBT_PLAN_CONVERT is set.
 static bool load_plan(vbt_model* m, const char* path) {
-  FILE* f = fopen(path, "r");
-  if (!f) return false;
-  char head[32] = "";
-  int ng = 0;
-  bool v2 = false;
-  bool ok = fscanf(f, "%31s", head) == 1;
-  if (ok && strcmp(head, "VBTPLAN2") == 0) { v2 = true; ok = fscanf(f, "%d", &ng) == 1; }
-  else if (ok) ng = atoi(head);
-  ok = ok && ng == (int)m->groups.size();
-  std::vector<std::pair<int, std::vector<int>>> sel;
-  for (int gi = 0; ok && gi < ng; gi++) {
-    int ch = 0, ns = 0;
-    ok = fscanf(f, "%d %d", &ch, &ns) == 2 && ch >= 0 && ch < (int)m->groups[gi].alts.size() && ns == (int)m->groups[gi].alts[ch].steps.size();
-    std::vector<int> v(ok ? ns : 0);
-    for (int i = 0; ok && i < ns; i++) {
-      if (v2) {
-        char tok[96] = "";
-        ok = fscanf(f, "%95s", tok) == 1;
-        char* colon = ok ? strrchr(tok, ':') : nullptr;
-        ok = ok && colon != nullptr;
-        if (ok) {
-          *colon = 0;
-          v[i] = atoi(colon + 1);
-          const int fam = m->groups[gi].alts[ch].steps[i].family;
-          if (strcmp(tok, kFamilyName[fam]) != 0) {
-            fprintf(stderr, "[vbt] plan %s: group %d step %d is '%s' in the file, '%s' in this library - plan refused, re-tuning\n", path, gi, i, tok, kFamilyName[fam]);
-            ok = false;
-          }
-        }
-      } else {
-        ok = fscanf(f, "%d", &v[i]) == 1;
+  // the shape a file may select from: this library's groups, their alternatives, the family of every step and the variants the planner
+  // offers for it (container_parse.h: parse_plan_file refuses everything else, and the model is tuned afresh)
+  PlanShape shape;
+  for (const Group& g : m->groups) {
+    std::vector<std::vector<PlanStepShape>> alts;
+    for (const Alt& a : g.alts) {
+      std::vector<PlanStepShape> steps;
+      for (const Step& st : a.steps) {
+        PlanStepShape ps;
+        ps.family = kFamilyName[st.family];
+        ps.variants = candidate_variants(m, st);
+        // the fused tile kernels read their variant as a set of flags (matrix-pipe depthwise, half-height tile, 48-channel chunks,
+        // 128-pixel tiles ...), each guarded by its own fit test in launch_step: plans searched under load (tools/tune_under_load.py)
+        // hold combinations the isolated autotuner does not time
+        if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE)
+          for (int v = 0; v < 32; v++)
+            if (std::find(ps.variants.begin(), ps.variants.end(), v) == ps.variants.end()) ps.variants.push_back(v);
+        if (std::find(ps.variants.begin(), ps.variants.end(), -1) == ps.variants.end()) ps.variants.push_back(-1);
+        if (std::find(ps.variants.begin(), ps.variants.end(), st.variant) == ps.variants.end()) ps.variants.push_back(st.variant);   // the heuristic plan's own choice
+        steps.push_back(ps);
       }
+      alts.push_back(steps);
     }
-    sel.push_back({ch, v});
+    shape.groups.push_back(alts);
   }
-  fclose(f);
-  if (!ok) return false;
-  for (int gi = 0; gi < ng; gi++) {
-    m->groups[gi].chosen = sel[gi].first;
-    Alt& a = m->groups[gi].alts[sel[gi].first];
-    for (size_t i = 0; i < a.steps.size(); i++) a.steps[i].variant = sel[gi].second[i];
+  std::vector<PlanChoice> sel;
+  std::string note;
+  if (!parse_plan_file(path, shape, &sel, &note)) {
+    if (note != "no such file") fprintf(stderr, "[vbt] plan %s: %s - plan refused, re-tuning\n", path, note.c_str());
+    return false;
+  }
+  for (size_t gi = 0; gi < m->groups.size(); gi++) {
+    m->groups[gi].chosen = sel[gi].chosen;
+    Alt& a = m->groups[gi].alts[(size_t)sel[gi].chosen];
+    for (size_t i = 0; i < a.steps.size(); i++) a.steps[i].variant = sel[gi].variants[i];
   }
   return true;
 }
@@ -2471,21 +2473,17 @@ int vbt_model_num_launches(const vbt_model* m) { return m ? (int)m->steps.size()
 int vbt_model_create_ex(const char* path, int device, int max_batch, int flags, vbt_model** out) {
   if (!path || !out || max_batch < 1) { set_error("vbt_model_create: bad argument"); return VBT_ERR_ARG; }
   *out = nullptr;
-  FILE* f = fopen(path, "rb");
-  if (!f) { set_error("cannot open model container '%s'", path); return VBT_ERR_IO; }
   vbt_model* m = new vbt_model();
-  bool ok = fread(&m->hdr, sizeof(Header), 1, f) == 1 && memcmp(m->hdr.magic, VBT_CONTAINER_MAGIC, 8) == 0;
-  if (ok) {
-    m->tensors.resize(m->hdr.num_tensors);
-    m->ops.resize(m->hdr.num_ops);
-    m->blob.resize(m->hdr.blob_bytes);
-    ok = fread(m->tensors.data(), sizeof(TensorRec), m->tensors.size(), f) == m->tensors.size() &&
-         fread(m->ops.data(), sizeof(OpRec), m->ops.size(), f) == m->ops.size() &&
-         fseek(f, (long)m->hdr.blob_offset, SEEK_SET) == 0 &&
-         fread(m->blob.data(), 1, m->blob.size(), f) == m->blob.size();
+  {
+    // reader + structural validation (container_parse.h): every index the planner and the kernels follow is in range before they see it
+    ContainerData cd;
+    std::string why;
+    if (!read_container(path, &cd, &why)) { delete m; set_error("%s", why.c_str()); return VBT_ERR_IO; }
+    m->hdr = cd.hdr;
+    m->tensors.swap(cd.tensors);
+    m->ops.swap(cd.ops);
+    m->blob.swap(cd.blob);
   }
-  fclose(f);
-  if (!ok) { delete m; set_error("'%s' is not a valid " VBT_CONTAINER_MAGIC " container (older containers: regenerate with tools/make_model.py)", path); return VBT_ERR_IO; }
   m->device = device;
   m->max_batch = max_batch;
   m->flags = flags;

@@ -750,7 +750,8 @@ __global__ __launch_bounds__(256) void resize_kernel(const int8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// TFLite_Detection_PostProcess (fast single-class path): one workgroup per frame.
+// TFLite_Detection_PostProcess (fast path, max_classes_per_detection = 1: every anchor scores with the best of its C class columns, then
+// single-class NMS): one workgroup per frame.
 // ------------------------------------------------------------------------------------------
 struct PostArgs {
   const int8_t* cls[5];
@@ -764,6 +765,7 @@ struct PostArgs {
   const unsigned char* tables;
   int A, max_det, qmin;  // qmin: lowest RANK byte whose score >= nms_score_threshold (128 = none)
   float iou_thr;
+  int C;                 // class columns per anchor: the class tensors are [h][w][anchors_per_location * C], anchor a's bytes are contiguous
 };
 constexpr int POST_CAP = 2048;
 // Phase timers (developer builds only: VBT_EXTRA_CXXFLAGS=-DVBT_POST_PROF): s_memtime deltas of workgroup 0, thread 0, summed per phase;
@@ -854,14 +856,14 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
   const unsigned char *pc0, *pb0;
   long ce1, ce2, ce3, ce4, be1, be2, be3, be4;
   {
-    auto cbias = [&](int l) { return (long)p.cls[l] + b * (long)(p.base[l + 1] - p.base[l]) - p.base[l]; };
+    auto cbias = [&](int l) { return (long)p.cls[l] + (b * (long)(p.base[l + 1] - p.base[l]) - p.base[l]) * (long)p.C; };
     auto bbias = [&](int l) { return (long)p.box[l] + (b * (long)(p.base[l + 1] - p.base[l]) - p.base[l]) * 4; };
     pc0 = (const unsigned char*)cbias(0); pb0 = (const unsigned char*)bbias(0);
     ce1 = cbias(1) - cbias(0); ce2 = cbias(2) - cbias(1); ce3 = cbias(3) - cbias(2); ce4 = cbias(4) - cbias(3);
     be1 = bbias(1) - bbias(0); be2 = bbias(2) - bbias(1); be3 = bbias(3) - bbias(2); be4 = bbias(4) - bbias(3);
   }
-  auto cls_ptr = [&](int a) -> const unsigned char* {      // address of anchor a's class byte
-    long o = a;
+  auto cls_ptr = [&](int a) -> const unsigned char* {      // address of anchor a's class byte(s)
+    long o = (long)a * p.C;
     o += a >= b1 ? ce1 : 0l; o += a >= b2 ? ce2 : 0l; o += a >= b3 ? ce3 : 0l; o += a >= b4 ? ce4 : 0l;
     return pc0 + o;
   };
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
       if (4 * i + e < A) w |= (unsigned)*cls_ptr(4 * i + e) << (8 * e);
     return w;
   };
-  {
+  if (p.C == 1) {
     unsigned w[PS];
 #pragma unroll
     for (int k = 0; k < PS; k++)      // (a dword that will be patched reads the aligned dword around its first byte: inside the arena)
@@ -893,6 +895,23 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
 #pragma unroll 1
     for (int i = tid; i < n4; i += NT)
       if (!whole(i, cls_ptr(4 * i))) ((unsigned*)cb)[i] = patch(i);
+  } else {
+    // C class columns per anchor: the anchor scores with its best column (NonMaxSuppressionMultiClassFastHelper, one class per
+    // detection).  The LOGISTIC table is monotone, so the best score is the score of the largest byte; the byte array in LDS then is
+    // exactly the one-column case.  Four anchors per thread and pass: one dword of LDS.
+#pragma unroll 1
+    for (int i = tid; i < n4; i += NT) {
+      unsigned w = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int a = min(4 * i + e, A - 1);
+        const signed char* src = (const signed char*)cls_ptr(a);
+        int best = src[0];
+        for (int c = 1; c < p.C; c++) best = max(best, (int)src[c]);
+        w |= ((unsigned)best & 255u) << (8 * e);
+      }
+      ((unsigned*)cb)[i] = w;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) hist32[tid + NT * k] = 0;
@@ -1140,7 +1159,9 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
         bool alive = ci < n;
         float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
         float sc = 0.f;
+        int anchor = 0;
         if (alive) {
+          anchor = (int)(sk[ci] & 0xFFFFu);
           if (fast) { bx = lbox[ci]; sc = lsc[ci]; }
           else bx = decode(sk[ci], sc);
         }
@@ -1159,13 +1180,24 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
           sb.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx.w), j));
           const float ss = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), j));
           const float sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(area), j));
+          const int sel_anchor = __builtin_amdgcn_readlane(anchor, j);
           if (lane == 0) {
             selbox[nsel] = sb;
             selarea[nsel] = sa;
             float* bo = boxes + (b * p.max_det + nsel) * 4;
             bo[0] = sb.x; bo[1] = sb.y; bo[2] = sb.z; bo[3] = sb.w;
             scores[b * p.max_det + nsel] = ss;
-            classes[b * p.max_det + nsel] = 0.0f;
+            // detection class = ArgMaxVector over the float scores of the anchor's columns: the FIRST column on the best score's rank
+            int cls_id = 0;
+            if (p.C > 1) {
+              const unsigned char* src = cls_ptr(sel_anchor);
+              int best = -128;
+              for (int c = 0; c < p.C; c++) {
+                const int r = (int)s_rank[(int)(src[c] ^ 128u)];
+                if (r > best) { best = r; cls_id = c; }
+              }
+            }
+            classes[b * p.max_det + nsel] = (float)cls_id;
           }
           __threadfence_block();  // selbox[] is read by the other lanes of this wavefront
           nsel++;

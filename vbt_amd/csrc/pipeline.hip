@@ -79,10 +79,21 @@ struct vbt_pipeline {
   std::vector<int> row_table;      // p(d) of the compact upload, for (row_H, row_h)
   int row_H = 0, row_h = 0;
   int frame_count = 0, step_idx = 0, last_B = 0;
-  uint64_t h2d_bytes = 0;
+  uint64_t h2d_bytes = 0, step_host_ns = 0, step_calls = 0;
 };
 
 namespace {
+
+// host time of a step call, for vbt_pipeline_info (is the host or the GPU pacing a small-batch run?)
+struct StepTimer {
+  vbt_pipeline* p;
+  std::chrono::steady_clock::time_point t0;
+  explicit StepTimer(vbt_pipeline* p_) : p(p_), t0(std::chrono::steady_clock::now()) {}
+  ~StepTimer() {
+    p->step_host_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    p->step_calls++;
+  }
+};
 
 #define PL_CHECK(expr)            \
   do {                            \
@@ -706,6 +717,7 @@ int vbt_pipeline_step(vbt_pipeline* p, const uint8_t* frames, int frames_on_devi
     for (int i = 0; i < p->n; i++)
       if (clip_map[i] >= p->n_trk) { set_error("vbt_pipeline_step: slot %d -> clip %d, the pipeline follows %d clips", i, clip_map[i], p->n_trk); return VBT_ERR_ARG; }
   if (!clip_map && track && p->n_trk > p->n) { set_error("vbt_pipeline_step: %d clips on %d slots needs clip_map / frame_idx (or vbt_pipeline_step_runs)", p->n_trk, p->n); return VBT_ERR_ARG; }
+  StepTimer timer(p);
   VBT_HIP_CHECK(hipSetDevice(p->device));
   const int o = p->step_idx % p->ring, k = o % p->depth;   // output slot; forward slot (model instance, stream)
   const bool plain = !clip_map && !active && track;
@@ -779,6 +791,7 @@ int vbt_pipeline_step_runs(vbt_pipeline* p, const uint8_t* frames, const uint8_t
     return VBT_ERR_ARG;
   }
   if ((src_h > 0) != (src_w > 0)) { set_error("vbt_pipeline_step_runs: src_h and src_w come together"); return VBT_ERR_ARG; }
+  StepTimer timer(p);
   VBT_HIP_CHECK(hipSetDevice(p->device));
   std::vector<vbt_run> ra(runs, runs + n_runs);
   int B = 0;
@@ -833,6 +846,7 @@ int vbt_pipeline_reset(vbt_pipeline* p) {
   std::fill(p->trk_ev_of.begin(), p->trk_ev_of.end(), -1);
   p->last_trk = -1;
   std::fill(p->clip_frames.begin(), p->clip_frames.end(), 0);
+  p->step_host_ns = p->step_calls = 0;
   return VBT_OK;
 }
 
@@ -930,6 +944,8 @@ int vbt_pipeline_get_info(const vbt_pipeline* p, vbt_pipeline_info* out) {
   out->copy_stream = (void*)p->copy_stream;
   out->tracker_stream = (void*)p->trk_stream;
   out->h2d_bytes = p->h2d_bytes;
+  out->step_host_ns = p->step_host_ns;
+  out->step_calls = p->step_calls;
   return VBT_OK;
 }
 

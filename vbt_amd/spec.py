@@ -37,7 +37,11 @@ ACT_RELU6 = 1
 
 MAX_DETECTIONS = 25          # pinned by reference dfs/eval_detections.pkl.gz (61 x 25 rows / model)
 NUM_ANCHORS_PER_LOC = 9      # 3 octave scales x 3 aspect ratios
-NUM_CLASSES = 1              # reference train.py:34
+# Class columns per anchor in the head's class tensors.  reference train.py:30-46 trains ONE label, `label_map={1: "barbell"}`, with
+# tflite-model-maker, whose EfficientDet head has max(label id) + 1 columns (label ids are 1-based, column 0 is never a target): TWO.
+# Pinned by the converter's op counts in reference models/*.log:110 (1.752 / 3.547 / 6.066 G): only the two-column class net reproduces
+# all three to the printed digits under the converter's counting rule (tflite_arithmetic_ops below, tests/test_spec.py).
+NUM_CLASSES = 2
 
 
 @dataclass
@@ -215,6 +219,26 @@ class Graph:
             n += op.weight_elems(self.tensors)
         return n
 
+    def tflite_arithmetic_ops(self) -> int:
+        """"Estimated count of arithmetic ops" as the TFLite converter prints it when it exports a model (reference
+        models/efficientdet_lite0_whole.log:110 and the two sibling logs) [EXTERNAL: TFLite MLIR converter, the per-op
+        GetArithmeticCount rules]: CONV_2D / DEPTHWISE_CONV_2D 2 x MACs + one bias add per output element; ADD one per output
+        element; MAX_POOL_2D filter_h x filter_w per output element; LOGISTIC 64 per element (on the concatenated class scores);
+        QUANTIZE / DEQUANTIZE / RESIZE_NEAREST_NEIGHBOR / RESHAPE / CONCATENATION / the post-process custom op count nothing."""
+        T = self.tensors
+        n = 0
+        for op in self.ops:
+            o = T[op.output]
+            if op.type in (OP_STEM, OP_PW, OP_DW):
+                n += 2 * op.macs(T) + o.elems
+            elif op.type == OP_ADD:
+                n += o.elems
+            elif op.type == OP_MAXPOOL:
+                n += o.elems * op.k * op.k
+            elif op.type == OP_POSTPROCESS:
+                n += 64 * sum(T[t].elems for t in op.inputs[:len(op.inputs) // 2])
+        return n
+
     def num_anchors(self) -> int:
         return sum(s * s for s in self.level_sizes()) * NUM_ANCHORS_PER_LOC
 
@@ -222,9 +246,10 @@ class Graph:
         return [math.ceil(self.cfg.image_size / 2 ** l) for l in range(3, 8)]
 
 
-def build_graph(arch: int) -> Graph:
+def build_graph(arch: int, num_classes: int = NUM_CLASSES) -> Graph:
     cfg = ARCHS[arch]
     g = Graph(cfg)
+    g.num_classes = int(num_classes)
     S = cfg.image_size
     x = g.tensor("image", S, S, 3)
 
@@ -298,7 +323,7 @@ def build_graph(arch: int) -> Graph:
     cls_out, box_out = [], []
     for li, f in enumerate(cur):
         lvl = li + 3
-        for head, cfin, outs in (("cls", NUM_ANCHORS_PER_LOC * NUM_CLASSES, cls_out),
+        for head, cfin, outs in (("cls", NUM_ANCHORS_PER_LOC * g.num_classes, cls_out),
                                  ("box", NUM_ANCHORS_PER_LOC * 4, box_out)):
             y = f
             for i in range(cfg.head_repeats):

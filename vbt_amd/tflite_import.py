@@ -225,9 +225,16 @@ def import_tflite(path):
     opts = flex_root(post_op.custom_options) if post_op.custom_options else {}
     if not isinstance(opts, dict):
         raise UnsupportedModel(f"{POSTPROCESS_NAME}: custom options are not a map")
+    # class predictions [1, A, C]: C = num_classes_with_background of detection_postprocess.cc; the op scores columns label_offset = C -
+    # num_classes onwards.  The reference's models (one label with id 1 under tflite-model-maker: two columns, num_classes = 2,
+    # vbt_amd/spec.py) have label_offset 0, and so must any model mapped here.
     num_classes = int(opts.get("num_classes", 1))
-    if num_classes != 1:
-        raise UnsupportedModel(f"num_classes = {num_classes}: the reference trains one class (train.py:34)")
+    cls_shape = list(T[post_op.inputs[1]].shape)
+    n_cols = int(cls_shape[2]) if len(cls_shape) == 3 else 1
+    if num_classes < 1 or num_classes > 4 or n_cols != num_classes:
+        raise UnsupportedModel(f"num_classes = {num_classes} with {n_cols} class columns: 1..4 classes without a background column are mapped")
+    if int(opts.get("max_classes_per_detection", 1)) != 1:
+        raise UnsupportedModel("max_classes_per_detection != 1")
     if bool(opts.get("use_regular_nms", False)):
         raise UnsupportedModel("use_regular_nms = true is not supported (fast NMS only)")
     max_det = int(opts.get("max_detections", spec.MAX_DETECTIONS))
@@ -458,9 +465,9 @@ def import_tflite(path):
                 t = int(r["inputs"][0])
     for li in range(5):
         c, b = tensors[tmap[cls_levels[li]]], tensors[tmap[box_levels[li]]]
-        if (c[0], c[1]) != (b[0], b[1]) or b[2] != 4 * c[2]:
-            raise UnsupportedModel("class / box head shapes do not match (A anchors x 1 class, A x 4)")
-    n_anch = sum(tensors[tmap[t]][0] * tensors[tmap[t]][1] * tensors[tmap[t]][2] for t in cls_levels)
+        if (c[0], c[1]) != (b[0], b[1]) or c[2] % num_classes or b[2] != 4 * (c[2] // num_classes):
+            raise UnsupportedModel(f"class / box head shapes do not match (A anchors x {num_classes} classes, A x 4)")
+    n_anch = sum(tensors[tmap[t]][0] * tensors[tmap[t]][1] * tensors[tmap[t]][2] // num_classes for t in cls_levels)
     if anchors.shape[0] != n_anch:
         raise UnsupportedModel(f"{anchors.shape[0]} anchors for {n_anch} head outputs")
     if max_det != spec.MAX_DETECTIONS:
@@ -492,7 +499,7 @@ def import_tflite(path):
     arch = {320: 0, 384: 1, 448: 2}.get(S, -1)
     header = dict(arch=arch, image_size=S, num_anchors=n_anch, max_detections=max_det,
                   nms_iou_threshold=float(opts.get("nms_iou_threshold", 0.5)),
-                  nms_score_threshold=float(opts.get("nms_score_threshold", 0.0)), input_tensor=in_container or 0)
+                  nms_score_threshold=float(opts.get("nms_score_threshold", 0.0)), input_tensor=in_container or 0, num_classes=num_classes)
     if in_container != 0:
         raise UnsupportedModel("the quantised image must be the first activation of the graph")
     return header, tarr, oarr, blob.bytes()
