@@ -95,7 +95,7 @@ def test_one_clip_time_batched_equals_per_frame_and_oracle(oracle_lib, model_pat
     ref.finish()
     want = ref.rows(0)
     want_ph = ref.phases(0)
-    assert len(want["id"]) > 50
+    assert len(want["id"]) > 30
     host = torch.from_numpy(frames).pin_memory()
     for mode in ("device", "host", "device_sources", "host_sources"):
         pipe = Pipeline(model_path, F, max_frames=T, fps=60.0, rows_per_frame=25, tracker_clips=1)
@@ -200,7 +200,7 @@ def test_config2_full_length_clip(model_path):
         ref.step(fd[t:t + 1])
     rb, rr, rn, ro, rph = ref.close(cap=512)
     rc, rrows = ref.rows_all()
-    assert rr[0] > 1500 and rn[0] >= 2 and ro[0] == 0
+    assert rr[0] > 1000 and rn[0] >= 2 and ro[0] == 0
     pipe = Pipeline(model_path, F, max_frames=T, fps=60.0, tracker_clips=1)
     for t0 in range(0, T, F):
         pipe.step_runs(fd[t0:t0 + F], [(0, 0, F, t0 + 1)])

@@ -119,22 +119,27 @@ __device__ __forceinline__ uint4 band_source16(const BandArgs& a, int j, long b,
 // NW waves per workgroup: 16 for a BiFPN node (one or two workgroups per image: the per-wave chain of units must be short), 8 for
 // the head layers (1280+ bands per launch: 16-wave workgroups fill every wave slot of a CU with two of them, so a third forward
 // in flight cannot co-reside; 8 waves on bands of <= 240 pixels interleave twice as many phases - +1.3 % end to end).
-// C64: the map has 64 channels (Lite0): row stride, channel groups and K-steps are compile-time constants (the generic
-// form costs the Lite0 pipeline 3 % end to end: 95.0 k vs 98.0 k frames/s).
+// CT: channels of the map as a compile-time constant - 64 (Lite0) or 112 (Lite2); 0 = any width (C % 8 == 0) from the arguments.  With CT the
+// row stride, channel groups, K-steps and 16-byte pieces per pixel are constants (the generic form costs the Lite0 pipeline 3 % end to end:
+// 95.0 k vs 98.0 k frames/s; Lite2's 112-channel kernels ran 116 M scalar and 248 M vector instructions per forward on it, against a
+// requantisation floor of about 50 M).
 // NODES: the input may be a BiFPN node's sum of sources; false (the head-layer kernels) compiles that path - and its registers - out.
-template <int NW, bool C64, bool NODES = true>
+template <int NW, int CT, bool NODES = true>
 __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, unsigned char* bd_smem) {
   constexpr int nwaves = NW, nthreads = 64 * NW;
+  constexpr bool C64 = CT == 64, CK = CT != 0;                 // CK: the width is known at compile time
+  constexpr int CS_T = CT == 64 ? 80 : CT;                      // bytes per pixel row in LDS: an odd multiple of 16 >= C (64 -> 80, 112 -> 112)
+  static_assert(CT == 0 || CT == 64 || CT == 112, "compile-time widths: 64, 112");
   const long b = fdiv_small(local, frcp(a.nbands));
   const int band = local - (int)b * a.nbands;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;
   const int y0 = band * a.rows, nr = min(a.rows, a.H - y0);
   const int PW = a.W + 2, NPh = (nr + 2) * PW, NPo = nr * a.W, NPG = (NPo + 15) >> 4;
-  const int C = C64 ? 64 : a.C, CS = C64 ? 80 : a.CS;
+  const int C = CK ? CT : a.C, CS = CK ? CS_T : a.CS;
   unsigned char* T0 = bd_smem;
   unsigned char* D = T0 + (a.rows + 2) * PW * CS;
   unsigned char* WP = D + (((a.rows * a.W + 15) >> 4) << 4) * CS;   // NT x KS KB of weights | 512 B bias | 512 B mult
-  const int NT = (a.Cout + 15) >> 4, KS = C64 ? 1 : a.KS, NCG = C64 ? 4 : a.NCG;
+  const int NT = (a.Cout + 15) >> 4, KS = CK ? (CT + 63) / 64 : a.KS, NCG = CK ? (CT + 15) / 16 : a.NCG;
   unsigned char* WB = WP + NT * KS * 1024;
   BD_STAMP(0);
 
@@ -145,12 +150,12 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
   const float rcp_pw = frcp(PW);
   if (NODES && a.n_src > 0) {
     const bool up2[3] = {a.H == 2 * a.sh[0] && a.W == 2 * a.sw[0], a.H == 2 * a.sh[1] && a.W == 2 * a.sw[1], a.H == 2 * a.sh[2] && a.W == 2 * a.sw[2]};
-    if (C64 || (C & 15) == 0) {
+    if (CK || (C & 15) == 0) {
       // 16 channels of one pixel per lane-iteration (the stage used to walk dwords: four times the address arithmetic and four
       // times the dependent rounds of global loads - it was two thirds of a node kernel's time, tools/probes/bd_probe.hip); the
       // source loads of an iteration are all requested before its sums are formed
       constexpr int LITN = C64 ? BD_LIT_NODE : BD_LIT_NODE_WIDE;
-      const int npp = C64 ? 4 : CS >> 4, nreal = C64 ? 4 : C >> 4;   // 16-byte pieces per LDS pixel row / of real channels
+      const int npp = C64 ? 4 : CS >> 4, nreal = C64 ? 4 : C >> 4;   // 16-byte pieces per LDS pixel row / of real channels (constants under CT)
       const float rcp_npp = frcp(npp);
       const int total = NPh * npp;
       for (int i0 = tid; i0 < total; i0 += LITN * nthreads) {
@@ -159,7 +164,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #pragma unroll
         for (int k = 0; k < LITN; k++) {
           const int i = i0 + k * nthreads, ic = min(i, total - 1);
-          const int p = C64 ? ic >> 2 : fdiv_small(ic, rcp_npp), sg = ic - p * npp;
+          const int p = C64 ? ic >> 2 : (CK ? ic / (CS_T >> 4) : fdiv_small(ic, rcp_npp)), sg = ic - p * npp;
           const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
           const int iy = y0 + hy - 1, ix = hx - 1;
           const bool in = i < total && sg < nreal && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
@@ -236,7 +241,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
           if (pofs[k] >= 0) *(uint4*)(T0 + pofs[k]) = v[k];
       }
     } else {
-    if ((C & 15) == 0) {
+    if (CK || (C & 15) == 0) {
       // 16-byte pieces, BD_LIT loads in flight (Lite2's 112-channel maps: the 8-byte walk below was nine dependent rounds of loads per band)
       const int npp = CS >> 4, nreal = C >> 4;
       const float rcp_npp = frcp(npp);
@@ -248,7 +253,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
 #pragma unroll
         for (int k = 0; k < BD_LIT; k++) {
           const int i = i0 + k * nthreads, ic = min(i, total - 1);
-          const int p = fdiv_small(ic, rcp_npp), sg = ic - p * npp;
+          const int p = CK ? ic / (CS_T >> 4) : fdiv_small(ic, rcp_npp), sg = ic - p * npp;
           const int hy = fdiv_small(p, rcp_pw), hx = p - hy * PW;
           const int iy = y0 + hy - 1, ix = hx - 1;
           pofs[k] = i < total ? p * CS + 16 * sg : -1;
@@ -374,7 +379,7 @@ __device__ __forceinline__ void sepconv_band_body(const BandArgs& a, int local, 
       if (pg < NPG) p_units(full_c, std::integral_constant<int, 1>{}, pg);
     };
     rq_dispatch(a.rqp, p_walk);
-  } else if (!C64 && NT <= nwaves && KS <= 2 && (nwaves - NT * (nwaves / NT)) * 8 <= nwaves) {   // (maps of more than 64 channels; at most an eighth of the waves without a tile)
+  } else if (!C64 && NT <= nwaves && KS <= 2 && (nwaves - NT * (nwaves / NT)) * 8 <= nwaves) {   // (KS is a constant under CT)   // (maps of more than 64 channels; at most an eighth of the waves without a tile)
     // any other width (Lite1 / Lite2 maps, the heads' 9- / 36-channel outputs): wave w owns output tile w % NT and, of the pixel groups,
     // every (NW / NT)-th one, so its weights / bias / multipliers are loop invariants held in registers (the unit loop below re-read
     // them from LDS and re-derived (pixel group, tile) per unit: 40 vector instructions and 6 LDS reads per unit against 22 and 2)
@@ -444,21 +449,30 @@ __device__ __forceinline__ int band_problem(const MultiTiles& mt) {
 __global__ __launch_bounds__(64 * BD_HEAD_WAVES) void sepconv_band_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   const int pi = band_problem(mt);
-  sepconv_band_body<BD_HEAD_WAVES, true, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+  sepconv_band_body<BD_HEAD_WAVES, 64, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
 __global__ __launch_bounds__(64 * BD_HEAD_WAVES_WIDE, 2) void sepconv_band_wide_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
   const int pi = band_problem(mt);
-  sepconv_band_body<BD_HEAD_WAVES_WIDE, false, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+  sepconv_band_body<BD_HEAD_WAVES_WIDE, 0, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
+}
+__global__ __launch_bounds__(64 * BD_HEAD_WAVES_WIDE, 2) void sepconv_band_c112_kernel(const BandArgs* __restrict__ probs, MultiTiles mt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+  const int pi = band_problem(mt);
+  sepconv_band_body<BD_HEAD_WAVES_WIDE, 112, false>(probs[pi], (int)blockIdx.x - mt.start[pi], bd_smem_dyn);
 }
 // One problem (a BiFPN node): the arguments travel in the kernel-argument segment, one dependent memory round trip
 // less at the head of a kernel that is a chain of round trips.
 __global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_kernel(BandArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
-  sepconv_band_body<BD_WAVES, true>(a, (int)blockIdx.x, bd_smem_dyn);
+  sepconv_band_body<BD_WAVES, 64>(a, (int)blockIdx.x, bd_smem_dyn);
 }
 __global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_wide_kernel(BandArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
-  sepconv_band_body<BD_WAVES, false>(a, (int)blockIdx.x, bd_smem_dyn);
+  sepconv_band_body<BD_WAVES, 0>(a, (int)blockIdx.x, bd_smem_dyn);
+}
+__global__ __launch_bounds__(BD_THREADS) void sepconv_band_one_c112_kernel(BandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bd_smem_dyn[];
+  sepconv_band_body<BD_WAVES, 112>(a, (int)blockIdx.x, bd_smem_dyn);
 }
 #endif  // VBT_DEFINE_BAND_KERNELS

@@ -10,19 +10,25 @@ static int band_attrs() {
   VBT_LDS_OPT_IN(sepconv_band_one_kernel);
   VBT_LDS_OPT_IN(sepconv_band_wide_kernel);
   VBT_LDS_OPT_IN(sepconv_band_one_wide_kernel);
+  VBT_LDS_OPT_IN(sepconv_band_c112_kernel);
+  VBT_LDS_OPT_IN(sepconv_band_one_c112_kernel);
   return VBT_OK;
 }
 
 int launch_band_one(const BandArgs& a, unsigned grid, int lds_bytes, hipStream_t st) {
   if (band_attrs()) return VBT_ERR_HIP;
+  static const bool generic = getenv("VBT_BAND_GENERIC") != nullptr;   // (A/B knob: the any-width kernel on 112-channel maps)
   if (a.C == 64) sepconv_band_one_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
+  else if (a.C == 112 && a.CS == 112 && !generic) sepconv_band_one_c112_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
   else sepconv_band_one_wide_kernel<<<dim3(grid), BD_THREADS, lds_bytes, st>>>(a);
   return VBT_OK;
 }
 
 int launch_band_multi(const BandArgs* d_probs, const MultiTiles& mt, int C, unsigned grid, int lds_bytes, hipStream_t st) {
   if (band_attrs()) return VBT_ERR_HIP;
+  static const bool generic = getenv("VBT_BAND_GENERIC") != nullptr;
   if (C == 64) sepconv_band_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES, lds_bytes, st>>>(d_probs, mt);
+  else if (C == 112 && !generic) sepconv_band_c112_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES_WIDE, lds_bytes, st>>>(d_probs, mt);
   else sepconv_band_wide_kernel<<<dim3(grid), 64 * BD_HEAD_WAVES_WIDE, lds_bytes, st>>>(d_probs, mt);
   return VBT_OK;
 }
