@@ -459,3 +459,36 @@ def test_sixty_four_clips_without_torch(model_path, tmp_path):
         for a, b in zip(g[:6], (best, rows_n, nph, ovf, ph, counts)):
             assert np.array_equal(a, b), name
         assert g[6] == [rows[c, :counts[c]].tobytes() for c in range(n)], name
+
+
+@pytest.mark.parametrize("H,W", [(1280, 96), (960, 333), (700, 64), (1000, 41), (641, 80)])
+def test_host_frames_at_source_resolution_upload_only_the_rows_the_resize_reads(oracle_lib, model_path, H, W):
+    """N2 from host memory (the reference's situation: cap.read() hands over 1080 x 1920 frames, track.py:160): when the source holds more
+    than twice the network's rows, only the row pairs the bilinear resize of odt.py:15-16 reads are uploaded (vbt_amd/csrc/pipeline.hip:
+    one strided copy for integer scales - 1280 = 4 x 320, 960 = 3 x 320 where the two rows of a pair coincide -, a row table otherwise) and the
+    resize kernel indexes the compact buffer.  Detections == oracle preprocess + oracle detector, through step() and through step_runs() with
+    one host source per run; the uploaded byte count is the compact one."""
+    from oracle.preprocess import preprocess_image as ref_pre
+    from vbt_amd import mem
+    from vbt_amd.track import Pipeline
+    rng = np.random.default_rng(H + W)
+    n, T = 2, 2
+    src = rng.integers(0, 256, (T, n, H, W, 3), dtype=np.uint8)
+    src[..., : W // 2, :] = (src[..., : W // 2, :] // 64 * 64)             # flat regions next to noise: interpolated values on and off integers
+    pinned = mem.pinned_empty(src.shape)
+    pinned[...] = src
+    want_frames = np.stack([np.stack([ref_pre(src[t, c], (320, 320), swap_rb=True)[0] for c in range(n)]) for t in range(T)])
+    ob, os_, oc, on = oracle_lib.run_batch(model_path, want_frames.reshape(-1, 320, 320, 3), threads=8)
+    ob, os_, on = ob.reshape(T, n, 25, 4), os_.reshape(T, n, 25), on.reshape(T, n)
+    pipe = Pipeline(model_path, n, max_frames=T, fps=30.0, tracker_clips=n)
+    up0 = pipe.info().h2d_bytes
+    for t in range(T):
+        pipe.step(pinned[t], src_hw=(H, W), swap_rb=True)
+        b, s, c, k = pipe.detections()
+        assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t]), ("step", t)
+    assert pipe.info().h2d_bytes - up0 == T * n * 2 * 320 * W * 3          # row pairs, not T * n * H * W * 3
+    pipe.reset()
+    for t in range(T):                                                     # pageable numpy sources, one per run
+        pipe.step_runs([src[t, 0:1], src[t, 1:2]], [(0, 0, 1, t + 1), (1, 1, 1, t + 1)], src_hw=(H, W), swap_rb=True)
+        b, s, c, k = pipe.detections()
+        assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t]), ("step_runs", t)
