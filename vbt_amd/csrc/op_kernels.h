@@ -898,9 +898,8 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
   } else {
     // C class columns per anchor: the anchor scores with its best column (NonMaxSuppressionMultiClassFastHelper, one class per
     // detection).  The LOGISTIC table is monotone, so the best score is the score of the largest byte; the byte array in LDS then is
-    // exactly the one-column case.  Four anchors per thread and pass: one dword of LDS.
-#pragma unroll 1
-    for (int i = tid; i < n4; i += NT) {
+    // exactly the one-column case.
+    auto best4 = [&](int i) -> unsigned {       // dword i of the array, column by column (any C; the few dwords the fast path leaves)
       unsigned w = 0;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -910,7 +909,38 @@ __global__ __launch_bounds__(POST_THREADS) void postprocess_kernel(PostArgs p, f
         for (int c = 1; c < p.C; c++) best = max(best, (int)src[c]);
         w |= ((unsigned)best & 255u) << (8 * e);
       }
-      ((unsigned*)cb)[i] = w;
+      return w;
+    };
+    if (p.C == 2) {
+      // two columns (the reference's models): the 8 class bytes of 4 anchors are one 8-byte load where they lie inside one level at an
+      // 8-byte-aligned address (all PS loads of a thread in flight together); signed byte maxima of the pairs as packed-u16 maxima on the
+      // u8 image of the bytes.  Dwords that straddle two levels or sit at an odd offset (levels of 450 / 162 bytes per frame) are patched.
+      constexpr unsigned HB = 0x80808080u;
+      auto pair_max = [&](uint2 v) -> unsigned {
+        const unsigned w0 = v.x ^ HB, w1 = v.y ^ HB;
+        const unsigned m0 = pk_max_u16(w0 & 0x00FF00FFu, (w0 >> 8) & 0x00FF00FFu);   // bits 0-7: max(b0, b1), bits 16-23: max(b2, b3)
+        const unsigned m1 = pk_max_u16(w1 & 0x00FF00FFu, (w1 >> 8) & 0x00FF00FFu);
+        return ((m0 & 0xFFu) | ((m0 >> 8) & 0xFF00u) | ((m1 & 0xFFu) << 16) | ((m1 << 8) & 0xFF000000u)) ^ HB;
+      };
+      auto whole2 = [&](int i, const unsigned char* src) -> bool {
+        const int a = 4 * i;
+        return level_of(a) == level_of(a + 3) && a + 3 < A && (((unsigned long)src) & 7ul) == 0;
+      };
+      uint2 w[PS];
+#pragma unroll
+      for (int k = 0; k < PS; k++)
+        w[k] = *(const uint2*)((unsigned long)cls_ptr(4 * min(tid + NT * k, n4 - 1)) & ~7ul);
+#pragma unroll
+      for (int k = 0; k < PS; k++)
+        if (tid + NT * k < n4) ((unsigned*)cb)[tid + NT * k] = pair_max(w[k]);
+#pragma unroll 1
+      for (int i = tid + NT * PS; i < n4; i += NT) ((unsigned*)cb)[i] = pair_max(*(const uint2*)((unsigned long)cls_ptr(4 * i) & ~7ul));
+#pragma unroll 1
+      for (int i = tid; i < n4; i += NT)
+        if (!whole2(i, cls_ptr(4 * i))) ((unsigned*)cb)[i] = best4(i);
+    } else {
+#pragma unroll 1
+      for (int i = tid; i < n4; i += NT) ((unsigned*)cb)[i] = best4(i);
     }
   }
 #pragma unroll
