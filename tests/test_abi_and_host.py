@@ -225,3 +225,28 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
     assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
     assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "track_clip")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "examples", "track_clip.c"), "-I" + os.path.join(ROOT, "include"),
+                           "-L" + os.path.join(ROOT, "vbt_amd"), "-lvbt_hip", "-Wl,-rpath," + os.path.join(ROOT, "vbt_amd"), "-o", exe])
+    return exe
+
+
+def test_plain_c_host_builds_against_the_header_and_fails_loudly_without_a_gpu(tmp_path, model_path):
+    """The boundary is a C ABI, not a Python module: examples/track_clip.c - the clip loop of reference track.py:129-260 from a C host
+    (vbt_host_alloc, vbt_pipeline_create, vbt_track_clip) - compiles warning-free against include/vbt_hip.h and links against
+    libvbt_hip.so; without a GPU it exits non-zero with the library's message (no CPU fallback)."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    exe = _build_c_host(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run is covered by tests/test_gpu_cli.py")
+    raw = tmp_path / "clip.raw"
+    np.zeros((2, 320, 320, 3), np.uint8).tofile(raw)
+    p = subprocess.run([exe, model_path, str(raw), "2", "320", "320", "30"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and ("HIP" in p.stderr or "hip" in p.stderr), p.stderr

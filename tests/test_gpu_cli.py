@@ -73,3 +73,37 @@ def test_track_command_frame_stride_equals_track_function(tmp_path, model_path, 
     assert len(df) == len(wdf)
     for c in COLUMNS:
         assert np.array_equal(df[c].to_numpy(), wdf[c].to_numpy()), c
+
+
+@pytest.mark.parametrize("hw,stride", [((320, 320), 1), ((700, 96), 3)])
+def test_c_host_tracks_a_clip_like_the_python_wrapper(tmp_path, model_path, hw, stride):
+    """examples/track_clip.c (plain C over include/vbt_hip.h: pinned frames from vbt_host_alloc -> vbt_pipeline_create -> vbt_track_clip)
+    prints the same DataFrame rows, to the last bit, as vbt_amd.track.track_frames on the same clip - at the network resolution and at
+    a source resolution with a frame stride (row-pair upload + on-device resize, reference odt.py:10-19, track.py:166)."""
+    import subprocess
+    from test_abi_and_host import _build_c_host
+    from vbt_amd import synth
+    from vbt_amd.track import COLUMNS, track_frames
+    T = 40
+    H, W = hw
+    if hw == (320, 320):
+        frames = synth.clip_frames(21, 0, T)
+    else:
+        rng = np.random.default_rng(3)
+        frames = np.repeat(np.repeat(rng.integers(0, 256, (T, H // 4, W // 4, 3), dtype=np.uint8), 4, 1), 4, 2)
+    raw = tmp_path / "clip.raw"
+    np.ascontiguousarray(frames).tofile(raw)
+    exe = _build_c_host(tmp_path)
+    p = subprocess.run([exe, model_path, str(raw), str(T), str(H), str(W), "30", str(stride)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().split("\n")
+    assert lines[0] == ",".join(COLUMNS)
+    got = [ln.split(",") for ln in lines[1:]]
+    want = track_frames(frames, model_path, fps=30.0, frame_stride=stride, time_batch=64)
+    assert len(got) == len(want["id"])
+    for i, row in enumerate(got):
+        assert int(row[0]) == want["id"][i]
+        for j, k in enumerate(COLUMNS[1:]):
+            assert float(row[1 + j]) == want[k][i], (i, k)
+    if hw == (320, 320):
+        assert len(got) > 5
