@@ -46,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # before torch initialises HIP (see vbt_amd/__init__.py)
 # a pipeline whose busy streams share a hardware queue loses a third of its throughput: here that is an error, not a warning
-# (vbt_amd/track.py: _place_streams; the contract run falls back to the warning and says so in `stream_placement`)
+# (vbt_amd/csrc/pipeline.hip: place_streams; the contract run falls back to the note on stderr and says so in `stream_placement`)
 os.environ.setdefault("VBT_STRICT_PLACEMENT", "1")
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)

@@ -492,3 +492,88 @@ def test_host_frames_at_source_resolution_upload_only_the_rows_the_resize_reads(
         pipe.step_runs([src[t, 0:1], src[t, 1:2]], [(0, 0, 1, t + 1), (1, 1, 1, t + 1)], src_hw=(H, W), swap_rb=True)
         b, s, c, k = pipe.detections()
         assert np.array_equal(k, on[t]) and np.array_equal(s, os_[t]) and np.array_equal(b, ob[t]), ("step_runs", t)
+
+
+def test_pipeline_abi_refuses_bad_calls_and_stays_usable(model_path):
+    """Error behaviour of the vbt_pipeline_* entry points through ctypes: bad arguments come back as VBT_ERR_ARG (-1) with a message, a
+    too-small phase buffer as VBT_ERR_CAPACITY (-4), and the pipeline keeps working after every refusal."""
+    import ctypes
+    from vbt_amd import _lib, mem, synth
+    from vbt_amd.track import Pipeline
+    L = _lib.lib()
+    prm = _lib.PipelineParams()
+    L.vbt_pipeline_default_params(ctypes.byref(prm))
+    h = ctypes.c_void_p()
+    fps = np.array([30.0, 30.0])
+    prm.n_slots, prm.n_clips, prm.rows_cap = 0, 2, 100
+    assert L.vbt_pipeline_create(model_path.encode(), ctypes.byref(prm), fps.ctypes.data, ctypes.byref(h)) == -1 and not h.value
+    prm.n_slots = 2
+    bad_fps = np.array([30.0, 0.0])
+    assert L.vbt_pipeline_create(model_path.encode(), ctypes.byref(prm), bad_fps.ctypes.data, ctypes.byref(h)) == -1
+    assert L.vbt_pipeline_create(b"/nonexistent.vbtm", ctypes.byref(prm), fps.ctypes.data, ctypes.byref(h)) == -2
+    pipe = Pipeline(model_path, 2, max_frames=8, fps=30.0, rows_per_frame=25)
+    frames = np.stack([synth.render(synth.background(40 + c), 3 * c) for c in range(2)])
+    dev = mem.DeviceBuffer.from_host(frames)
+    p = pipe._h
+    assert L.vbt_pipeline_step(p, None, 1, 0, 0, 0, None, None, None, 1, None) == -1
+    assert L.vbt_pipeline_step(p, dev.ptr, 1, 320, 0, 0, None, None, None, 1, None) == -1                  # src_h without src_w
+    cm = np.array([0, 5], np.int32)
+    fi = np.array([1, 1], np.int32)
+    assert L.vbt_pipeline_step(p, dev.ptr, 1, 0, 0, 0, None, cm.ctypes.data, fi.ctypes.data, 1, None) == -1   # clip 5 of 2
+    assert L.vbt_pipeline_step(p, dev.ptr, 1, 0, 0, 0, None, cm.ctypes.data, None, 1, None) == -1             # clip_map without frame_idx
+    runs = (_lib.Run * 2)(_lib.Run(0, 0, 1, 2, 1, 1, 30.0), _lib.Run(1, 1, 1, 2, 1, 1, 30.0))               # second run leaves the batch
+    assert L.vbt_pipeline_step_runs(p, dev.ptr, None, 1, runs, 2, 0, 0, 0, 1, None, None, None, None, None) == -1
+    assert b"outside" in L.vbt_last_error()
+    assert L.vbt_pipeline_step_runs(p, None, None, 1, runs, 1, 0, 0, 0, 1, None, None, None, None, None) == -1  # neither frames nor sources
+    assert int(pipe.info().steps_enqueued) == 0                          # nothing was enqueued by the refused calls
+    for t in range(3):
+        pipe.step(dev.ptr)
+    best, rows, nph, ovf = (np.zeros(2, np.int32) for _ in range(4))
+    ph = np.zeros((2, 1, 6))
+    rc = L.vbt_pipeline_close(p, best.ctypes.data, rows.ctypes.data, nph.ctypes.data, ovf.ctypes.data, ph.ctypes.data, 0)
+    assert rc == -1                                                      # cap 0 is not a buffer
+    best2, rows2, nph2, ovf2, ph2 = pipe.close(cap=16)                   # ... and the pipeline is still usable
+    assert int(rows2.sum()) >= 0 and np.all(ovf2 == 0)
+    with pytest.raises(_lib.VbtError):
+        pipe.tracker_only_steps(1, slot=99)
+
+
+def test_device_frames_are_read_after_the_callers_stream_has_produced_them(model_path, oracle_lib):
+    """vbt_pipeline_step with device frames: the forward waits for the point of `caller_stream` at which the call is made.  The frame
+    buffer is filled on a side stream BEHIND a long spin, then handed over with that stream: the detections are those of the frames
+    that arrive late, not of the zeros the buffer held when step() was called."""
+    import torch
+    from vbt_amd import synth
+    from vbt_amd.track import Pipeline
+    n = 2
+    frames = np.stack([synth.render(synth.background(60 + c), 5 * c) for c in range(n)])
+    want = oracle_lib.run_batch(model_path, frames, threads=2)
+    src = torch.from_numpy(frames).cuda()
+    buf = torch.zeros_like(src)
+    pipe = Pipeline(model_path, n, max_frames=4, fps=30.0)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(200_000_000)                                   # ~0.1 s of spinning in front of the copy
+        buf.copy_(src, non_blocking=True)
+    pipe.step(buf, stream=side.cuda_stream)
+    b, s, c, k = pipe.detections()
+    assert np.array_equal(k, want[3]) and np.array_equal(s, want[1]) and np.array_equal(b, want[0])
+    assert int(want[3].sum()) > 0
+
+
+def test_many_pipelines_in_one_process_share_the_classified_streams(model_path):
+    """The library's stream pool is per process and per device: pipelines created one after the other take their busy streams from the
+    hardware-queue groups classified once (vbt_amd/csrc/pipeline.hip), so the tenth pipeline is placed as well as the first and no more
+    than GPU_MAX_HW_QUEUES groups are ever seen."""
+    from vbt_amd.track import Pipeline
+    seen = []
+    for i in range(10):
+        pipe = Pipeline(model_path, 2, max_frames=4, fps=30.0, depth=3)
+        inf = pipe.info()
+        assert inf.placement_ok == 1, i
+        seen.append(int(inf.queue_groups_seen))
+        busy = {pipe._det_streams[k].cuda_stream for k in range(3)} | {pipe._copy_stream.cuda_stream}
+        assert len(busy) == 4
+        del pipe
+    assert max(seen) <= 4 and seen[-1] == seen[2]
