@@ -654,6 +654,38 @@ def other_configs(torch, dev):
                         "64 frames per tracker launch + clip close; compare with clip1_time_batched, whose synthetic detector keeps ~10 tracks alive"}
     guarded("clip1_reference_boxes", clip1_reference)
 
+    # ---- SURVEY 8b's fused entry point: vbt_track_clip - ONE call per clip, frames in pinned host memory, rows back - at the network
+    #      resolution and at the reference's source resolution (1920 x 1080: row-pair upload + on-device resize) ----
+    def track_clip_c_abi():
+        from vbt_amd import mem
+        res = {}
+        for name, T, H, W in (("net_320x320", 2048, 320, 320), ("src_1920x1080", 192, 1920, 1080)):
+            host = mem.pinned_empty((T, H, W, 3))
+            if (H, W) == (320, 320):
+                bg = synth.background(0)
+                for t in range(T):
+                    host[t] = synth.render(bg, t)
+            else:
+                rng = np.random.default_rng(7)
+                base = np.repeat(np.repeat(rng.integers(0, 256, (8, H // 8, W // 8, 3), dtype=np.uint8), 8, 1), 8, 2)
+                for t in range(T):
+                    host[t] = base[t % 8]
+            pipe = Pipeline(MODEL, 64, max_frames=T, fps=60.0, tracker_clips=1, rows_per_frame=25)
+            out = {}
+
+            def body():
+                out["rows"] = len(pipe.track_clip(host, src_hw=None if (H, W) == (320, 320) else (H, W))["id"])
+            body()
+            dt = _timed(torch, body)
+            res[name] = {"frames_per_s": T / dt, "ms_per_frame": dt / T * 1e3, "frames": T, "rows": out["rows"]}
+            del pipe, host
+            gc.collect()
+        return {"frames_per_s": res["net_320x320"]["frames_per_s"], **res,
+                "note": "vbt_track_clip (include/vbt_hip.h): the whole loop of reference track.py:129-260 for one clip in one C call - pinned host frames -> "
+                        "copy stream -> 64 consecutive frames per detector batch -> OC-SORT walk on the device -> rows on the host; the 1920 x 1080 clip uploads "
+                        "only the rows the bilinear resize reads"}
+    guarded("track_clip_c_abi", track_clip_c_abi)
+
     # ---- 64 clips x 4 consecutive frames per detector batch (B = 256): what time-batching adds on top of the clip batch ----
     def b64x4():
         n, F, T = 64, 4, 512
