@@ -40,7 +40,7 @@ static bool shape_of(const char* path, vbt::PlanShape* shape) {
       *colon = 0;
       vbt::PlanStepShape s;
       s.family = tok;
-      s.variants = {-1, 0, 1, 2, 3, 4, 5, 9, 11, 17, 25, 100, 101, 102, 103, 104, 106, 201, 202, 203, 204, 206};
+      s.variants = {-1, 0, 1, 2, 3, 4, 5, 6, 9, 11, 17, 25, 100, 101, 102, 103, 104, 106, 201, 202, 203, 204, 206};
       steps.push_back(s);
     }
     shape->groups.push_back(std::vector<std::vector<vbt::PlanStepShape>>((size_t)ch + 1, steps));

@@ -66,13 +66,13 @@ def test_every_tensor_bit_exact(model_path, frames, oracle_run, flags):
         assert np.array_equal(classes[b], oc)
 
 
-@pytest.mark.parametrize("env", [{"VBT_PW_VARIANT": "3"}, {"VBT_PW_VARIANT": "4"}, {"VBT_PW_VARIANT": "2"}, {"VBT_XD_VARIANT": "1"}, {"VBT_XD_VARIANT": "3"},
+@pytest.mark.parametrize("env", [{"VBT_PW_VARIANT": "3"}, {"VBT_PW_VARIANT": "4"}, {"VBT_PW_VARIANT": "2"}, {"VBT_PW_VARIANT": "5"}, {"VBT_PW_VARIANT": "6"}, {"VBT_XD_VARIANT": "1"}, {"VBT_XD_VARIANT": "3"},
                                  {"VBT_XD_VARIANT": "101"}, {"VBT_XD_VARIANT": "103"}, {"VBT_XD_VARIANT": "106", "VBT_PW_VARIANT": "4"},
                                  {"VBT_XD_VARIANT": "201"}, {"VBT_XD_VARIANT": "203"},
                                  {"VBT_SUBSTREAMS": "2"}, {"VBT_SUBSTREAMS": "3", "VBT_GRAPH_MAX_BATCH": "0"}])
 def test_forced_kernel_variants_bit_exact(model_path, frames, oracle_run, env):
     """Kernel variants the autotuner may or may not pick on a given day, forced through the test-only environment overrides (read
-    once per process, hence a child process per case): the large-K pointwise conv with its weights shared through LDS (3 / 4) or split
+    once per process, hence a child process per case): the large-K pointwise conv with its weights shared through LDS (3 / 4; 5 / 6: the block's whole weight panel in LDS and a K loop without barriers) or split
     over the waves (2), and both forms of the expand + depthwise kernel (chunks per workgroup; 100 + n = the second form on 8 waves, 200 + n on 16).  Every
     materialised tensor and every detection must equal the oracle's.
     VBT_SUBSTREAMS: the batch split over side streams (the merged lateral-conv launch holds whole-batch pointers and has to be

@@ -1910,6 +1910,18 @@ static int launch_step(vbt_model* m, const Step& s, int B, hipStream_t st, const
         dim3 grid((unsigned)((M + 64 * ms - 1) / (64 * ms)), (unsigned)s.NB);
         if (ms == 2) pw_d_kernel<2><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
         else pw_d_kernel<1><<<grid, 256, 0, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+      } else if (pw_variant == 5 || pw_variant == 6) {  // the block's whole weight panel in LDS, a K loop without barriers (pw_e_kernel), 64 / 128 pixels per workgroup
+        const int ms = pw_variant - 4;
+        const int lds = s.KS64 * 4096;
+        if (lds > 160 * 1024) { set_error("pw_conv: a weight panel of %d bytes does not fit the LDS", lds); return VBT_ERR_ARG; }
+        dim3 grid((unsigned)((M + 64 * ms - 1) / (64 * ms)), (unsigned)s.NB);
+        if (ms == 2) {
+          if (lds > 64 * 1024) VBT_LDS_OPT_IN(pw_e_kernel<2, 4>);
+          pw_e_kernel<2, 4><<<grid, 256, lds, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+        } else {
+          if (lds > 64 * 1024) VBT_LDS_OPT_IN(pw_e_kernel<1, 4>);
+          pw_e_kernel<1, 4><<<grid, 256, lds, st>>>(x, s.wp64, e, ra, out, M, K, s.KS64, N, s.NB);
+        }
       } else if (pw_variant == 2) {  // split-K over the 4 waves of a workgroup
         // one 64-channel block per workgroup (16 KB of LDS for the cross-wave reduction, twice the workgroups) rather than two
         // (32 KB): +1.4 % end to end with three forwards in flight - the workgroups of one launch then fit the CUs in one round
@@ -2234,7 +2246,7 @@ static std::vector<int> candidate_variants(const vbt_model* m, const Step& st) {
   } else if (st.family == F_PW && st.KS64 <= 4) {
     cand = {0, 1};
   } else if (st.family == F_PW) {
-    cand = {-1, 2, 3, 4};
+    cand = {-1, 2, 3, 4, 5, 6};
   } else if (st.family == F_MBCONV || st.family == F_SEPCONV || st.family == F_NODE) {
     cand = {0, 1, 3};   // VALU dw, matrix-pipe dw, matrix-pipe dw + half-height tile
     if (image_geom(m, st).ok) cand.push_back(5);  // one workgroup per image

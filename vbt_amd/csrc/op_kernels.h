@@ -329,6 +329,82 @@ __global__ __launch_bounds__(256) void pw_d_kernel(const int8_t* __restrict__ x,
   }
 }
 
+// variant E: the whole weight panel of the workgroup's 64-channel block - KS x 4 KB, 44 KB for K = 672, 72 KB for K = 1152 - goes to LDS ONCE, with
+// every load of a thread in flight together, then ONE barrier; the K loop has no barrier at all: per step a wave reads its four weight tiles from
+// LDS (4 x 1 KB at 128 B/clk) and issues 4 x MS MFMAs, with the activation operands PD steps ahead in registers.  Variant D meets at a
+// workgroup barrier once per K-step - 11 to 18 times per launch, four waves each time - and with one to three workgroups per CU nothing fills
+// those waits (rocprofv3: 9-10 us per launch for 2-4 GOP, the matrix pipe 5 % busy).  Measured (profiles/r05_ab.md 6): per launch the 20 x 20
+// projections gain 0-1.5 us and the 10 x 10 ones lose 2 us when timed alone, yet with three forwards in flight the plan that runs b6-b15 on this
+// variant is +0.6 % end to end in every round of the A/B - so the plan uses it, and the launches' 10 us are not their K loop (a variant that kept
+// the barrier but requested its loads four steps ahead measured the same).
+template <int MS, int PD>
+__global__ __launch_bounds__(256) void pw_e_kernel(const int8_t* __restrict__ x, const v4i* __restrict__ wp, Epi e, ResArgs ra,
+                                                   int8_t* __restrict__ out, long M, int K, int KS, int N, int NB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pwe_smem[];
+  v4i* wpanel = (v4i*)pwe_smem;   // [KS][4][64]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * (16 * MS);
+  const int nb = blockIdx.y;
+  // 1. the panel: KS x 256 operands of 16 bytes, thread t takes t, t + 256, ... - six at a time in flight
+  const v4i* wsrc = wp + (long)nb * KS * 4 * 64;
+  const int total = KS * 256;
+  for (int i0 = tid; i0 < total; i0 += 6 * 256) {
+    v4i v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = wsrc[min(i0 + k * 256, total - 1)];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (i0 + k * 256 < total) wpanel[i0 + k * 256] = v[k];
+  }
+  // 2. this wave's epilogue operands and the first PD activation operands, requested before the barrier
+  const int8_t* p[MS];
+  EpiRegs er[MS];
+#pragma unroll
+  for (int s = 0; s < MS; s++) {
+    const long mc = min(m0 + 16 * s + r, M - 1);
+    p[s] = x + mc * K + 16 * g;
+    load_epi(er[s], e, ra, mc, N, nb, g);
+  }
+  v4i aq[PD][MS];
+#pragma unroll
+  for (int i = 0; i < PD; i++) {
+    const int kn = min(i, KS - 1);
+#pragma unroll
+    for (int s = 0; s < MS; s++) aq[i][s] = ld16(p[s] + 64 * kn);
+  }
+  v4i acc[MS][4];
+#pragma unroll
+  for (int s = 0; s < MS; s++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[s][t] = (v4i){0, 0, 0, 0};
+  __syncthreads();
+  // 3. the K loop: no barrier
+  const v4i* wl = wpanel + lane;
+  for (int ks0 = 0; ks0 < KS; ks0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; j++) {
+      const int ks = ks0 + j;
+      if (ks < KS) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const v4i wv = wl[(ks * 4 + t) * 64];
+#pragma unroll
+          for (int s = 0; s < MS; s++) acc[s][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv, aq[j][s], acc[s][t], 0, 0, 0);
+        }
+      }
+      const int kn = min(ks + PD, KS - 1);
+#pragma unroll
+      for (int s = 0; s < MS; s++) aq[j][s] = ld16(p[s] + 64 * kn);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < MS; s++) {
+    const long m = m0 + 16 * s + r;
+    if (m < M) store_tile_e(acc[s], er[s], e, ra, out, m, N, nb, g);
+  }
+}
+
 __device__ __forceinline__ unsigned max4_s8(unsigned a, unsigned b) {
   unsigned r = 0;
 #pragma unroll
