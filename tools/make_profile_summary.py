@@ -17,7 +17,7 @@ import json
 import shutil
 import sys
 
-FAM = (("expdw_image", "fused_expand_dw"), ("expdw2_kernel", "fused_expand_dw"), ("pw_d", "pw_conv_mfma_i8"), ("pw_multi", "pw_conv_mfma_i8"), ("sepconv_band", "fused_sepconv_band"), ("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"),
+FAM = (("expdw_image", "fused_expand_dw"), ("expdw2_kernel", "fused_expand_dw"), ("pw_d", "pw_conv_mfma_i8"), ("pw_e", "pw_conv_mfma_i8"), ("pw_multi", "pw_conv_mfma_i8"), ("sepconv_band", "fused_sepconv_band"), ("fused_block_multi", "fused_heads_multi"), ("stem_block", "fused_stem_block"),
        ("mbconv_image", "fused_mbconv"), ("dw_tile", "dw_conv"), ("dw_col", "dw_conv"), ("dw_kernel", "dw_conv"),
        ("pw_a", "pw_conv_mfma_i8"), ("pw_b", "pw_conv_mfma_i8"), ("pw_c", "pw_conv_mfma_i8"), ("stem_kernel", "stem_conv_mfma_i8"),
        ("add_kernel", "add_requant"), ("maxpool", "maxpool3x3s2"), ("resize_kernel", "resize_nn"), ("postprocess", "decode_nms"),
