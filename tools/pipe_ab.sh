@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B on ONE box: the contract run (bench.py --contract-only, K = 20 and K = 400) of the tree in tools/scratch/old (a worktree of an
 # earlier commit with its own built library) against this tree, alternating, three rounds each.  gpurun_out/<tag>/ab.txt
+# Set-up (once, on the build host; tools/scratch/ is git-ignored but travels with gpurun):
+#   git worktree add -f tools/scratch/old <commit> && (cd tools/scratch/old && python -m vbt_amd.build && make -s -C oracle)
 TAG=${1:-ab}
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$PWD/gpurun_out/$TAG
